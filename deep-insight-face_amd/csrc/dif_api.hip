@@ -1,0 +1,131 @@
+// C ABI entry points (include/dif.h): error plumbing, distances, gallery + match.
+// The embedding network entry points live in net_api.hip.
+#include "../../include/dif.h"
+#include "dif_internal.hpp"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <new>
+
+namespace dif {
+
+static thread_local char g_err[1024] = "";
+
+int set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return -1;
+}
+
+static int check_metric(int metric) {
+  if (metric != DIF_METRIC_SQL2 && metric != DIF_METRIC_COSINE)
+    return set_error("Undefined distance metric %d", metric);   // evaluation/utility.py:64
+  return 0;
+}
+
+}  // namespace dif
+
+using namespace dif;
+
+struct dif_gallery {
+  Gallery g;
+};
+
+extern "C" {
+
+int dif_version(void) { return DIF_VERSION; }
+
+const char* dif_last_error(void) { return g_err; }
+
+int dif_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int dif_pairwise(const float* e1_dev, int64_t n1, const float* e2_dev, int64_t n2, int d, int metric,
+                 float* out_dev, void* stream) {
+  if (check_metric(metric)) return -1;
+  if (d <= 0) return set_error("dif_pairwise: d must be positive (got %d)", d);
+  if (n1 < 0 || n2 < 0) return set_error("dif_pairwise: negative row count");
+  if (n1 != n2 && n1 != 1 && n2 != 1)
+    return set_error("dif_pairwise: shapes (%lld,%d) and (%lld,%d) do not broadcast", (long long)n1, d,
+                     (long long)n2, d);
+  if (n1 == 0 || n2 == 0) return 0;
+  if (!e1_dev || !e2_dev || !out_dev) return set_error("dif_pairwise: null pointer");
+  return pairwise_run(e1_dev, n1, e2_dev, n2, d, metric, out_dev, (hipStream_t)stream);
+}
+
+int dif_gallery_create(dif_gallery** out, int d) {
+  if (!out) return set_error("dif_gallery_create: null out");
+  if (d <= 0 || d % 32 != 0)
+    return set_error("dif_gallery_create: embedding size must be a positive multiple of 32 (got %d)", d);
+  dif_gallery* h = new (std::nothrow) dif_gallery();
+  if (!h) return set_error("dif_gallery_create: out of host memory");
+  h->g.d = d;
+  *out = h;
+  return 0;
+}
+
+int dif_gallery_destroy(dif_gallery* h) {
+  if (!h) return 0;
+  Gallery& g = h->g;
+  if (g.rows) (void)hipFree(g.rows);
+  if (g.sq) (void)hipFree(g.sq);
+  if (g.ninv) (void)hipFree(g.ninv);
+  if (g.part_key) (void)hipFree(g.part_key);
+  if (g.part_idx) (void)hipFree(g.part_idx);
+  delete h;
+  return 0;
+}
+
+int dif_gallery_set(dif_gallery* h, const float* rows_dev, int64_t n, int64_t index_base, void* stream) {
+  if (!h) return set_error("dif_gallery_set: null handle");
+  if (n < 0) return set_error("dif_gallery_set: negative row count");
+  if (n > 0x7ffffff0LL) return set_error("dif_gallery_set: at most 2^31-16 rows per shard");
+  if (n > 0 && !rows_dev) return set_error("dif_gallery_set: null rows");
+  Gallery& g = h->g;
+  hipStream_t st = (hipStream_t)stream;
+  if (n > g.cap) {
+    DIF_HIP(hipStreamSynchronize(st));
+    if (g.rows) DIF_HIP(hipFree(g.rows));
+    if (g.sq) DIF_HIP(hipFree(g.sq));
+    if (g.ninv) DIF_HIP(hipFree(g.ninv));
+    g.rows = g.sq = g.ninv = nullptr;
+    g.cap = 0;
+    DIF_HIP(hipMalloc(&g.rows, (size_t)n * g.d * sizeof(float)));
+    DIF_HIP(hipMalloc(&g.sq, (size_t)n * sizeof(float)));
+    DIF_HIP(hipMalloc(&g.ninv, (size_t)n * sizeof(float)));
+    g.cap = n;
+  }
+  g.n = n;
+  g.index_base = index_base;
+  if (n == 0) return 0;
+  DIF_HIP(hipMemcpyAsync(g.rows, rows_dev, (size_t)n * g.d * sizeof(float), hipMemcpyDeviceToDevice, st));
+  return gallery_norms(&g, st);
+}
+
+int64_t dif_gallery_size(const dif_gallery* h) { return h ? h->g.n : 0; }
+
+int dif_match(dif_gallery* h, const float* probes_dev, int n, int metric, int64_t* idx_out_dev,
+              float* dist_out_dev, float* key_out_dev, void* stream) {
+  if (!h) return set_error("dif_match: null handle");
+  if (check_metric(metric)) return -1;
+  if (n < 0) return set_error("dif_match: negative probe count");
+  if (n == 0) return 0;
+  if (!probes_dev || !idx_out_dev || !dist_out_dev) return set_error("dif_match: null pointer");
+  return match_run(&h->g, probes_dev, n, metric, idx_out_dev, dist_out_dev, key_out_dev, (hipStream_t)stream);
+}
+
+int dif_match_merge(const float* keys_dev, const int64_t* idx_dev, const float* dist_dev, int R, int n,
+                    int64_t* idx_out_dev, float* dist_out_dev, void* stream) {
+  if (R <= 0 || n < 0) return set_error("dif_match_merge: bad sizes R=%d n=%d", R, n);
+  if (n == 0) return 0;
+  if (!keys_dev || !idx_dev || !dist_dev || !idx_out_dev || !dist_out_dev)
+    return set_error("dif_match_merge: null pointer");
+  return match_merge_run(keys_dev, idx_dev, dist_dev, R, n, idx_out_dev, dist_out_dev, (hipStream_t)stream);
+}
+
+}  // extern "C"

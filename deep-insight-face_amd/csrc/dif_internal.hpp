@@ -1,0 +1,40 @@
+// Internal declarations shared by the translation units of libdif.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+namespace dif {
+
+int set_error(const char* fmt, ...);   // records the message for dif_last_error(), returns -1
+
+#define DIF_HIP(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess)                                                                      \
+      return ::dif::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+// ---- gallery (owned copy of the rows + per-row norms + match workspace)
+struct Gallery {
+  int d = 0;
+  int64_t n = 0;
+  int64_t cap = 0;
+  int64_t index_base = 0;   // global index of row 0 (gallery sharded across ranks)
+  float* rows = nullptr;    // [n][d]
+  float* sq = nullptr;      // |g|^2
+  float* ninv = nullptr;    // -1/|g|
+  float* part_key = nullptr;
+  int* part_idx = nullptr;
+  size_t part_cap = 0;
+};
+
+int gallery_norms(Gallery* g, hipStream_t st);
+int match_run(Gallery* g, const float* probes, int B, int metric, int64_t* idx_out, float* dist_out,
+              float* key_out, hipStream_t st);
+int pairwise_run(const float* e1, int64_t n1, const float* e2, int64_t n2, int D, int metric, float* out,
+                 hipStream_t st);
+int match_merge_run(const float* keys, const int64_t* idx, const float* dist, int R, int B, int64_t* idx_out,
+                    float* dist_out, hipStream_t st);
+
+}  // namespace dif

@@ -1,0 +1,167 @@
+// fp32 MFMA tile mainloop for gfx950 (MI355X), shared by the implicit-GEMM
+// convolution, the embedding x gallery match and the ArcMargin logits kernels.
+//
+// Arithmetic: v_mfma_f32_32x32x2_f32 -- f32 in, f32 accumulate, bit-exact f32 fma
+// chain (MI355X_MICROARCH.md "Matrix cores"); peak 157.3 TFLOP/s.  This is the
+// parity path: the reference computes in float32 throughout.
+//
+// Geometry: 256 threads = 4 waves arranged 2 (M) x 2 (N); each wave owns WM x WN
+// MFMA tiles of 32x32, so the block tile is BM = 64*WM rows x BN = 64*WN columns.
+// K advances in steps of BK = 32 floats.  Operand tiles are staged
+// global -> registers -> LDS (16-byte chunks, so the A loader can synthesise the
+// zero halo of a convolution) into two LDS buffers: the loads of step k+1 are
+// issued before the MFMAs of step k and written to the other buffer after them,
+// one barrier per step.
+//
+// LDS image: [row][BK + 4] floats (144-byte rows).  A wave's ds_read_b128 then
+// touches 16 distinct 16-byte slots per 16-lane group (rows distinct mod 16) --
+// conflict-free; ds_write_b128 writes whole 128-byte rows per 8-lane group.
+//
+// Operand maps (cdna_hip_programming.md section 3): A lane l holds A[i = l&31][k = l>>5],
+// B lane l holds B[k = l>>5][j = l&31]; D lane l, reg r holds
+// D[i = (r&3) + 8*(r>>2) + 4*(l>>5)][j = l&31].  Any permutation of k applied to A
+// and B alike leaves the product unchanged, so lane-half h consumes k = 16*s + 8*h + t
+// (t = 0..7) in sub-step s: 32 contiguous bytes per lane, two ds_read_b128.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dif {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 32;               // floats per K-step
+constexpr int LDS_STRIDE = BK + 4;   // floats per LDS row (144 B)
+constexpr int NTHREADS = 256;
+
+template <int WM, int WN>
+struct Tile {
+  static constexpr int BM = 64 * WM;
+  static constexpr int BN = 64 * WN;
+  static constexpr int NA = BM / 32;  // 16-B chunks of A per thread per K-step
+  static constexpr int NB = BN / 32;
+  static constexpr int LDS_FLOATS = 2 * (BM + BN) * LDS_STRIDE;
+  static constexpr int LDS_BYTES = LDS_FLOATS * 4;
+};
+
+// D-fragment coordinates inside one 32x32 MFMA tile.
+__device__ __forceinline__ int frag_row(int lane, int reg) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+__device__ __forceinline__ int frag_col(int lane) { return lane & 31; }
+
+// Loader concept:
+//   struct L { __device__ void load(int kstep, f32x4 (&r)[N]); };
+// Row i of the thread's share is tile row (tid>>3) + 32*i, chunk (tid&7) of the
+// K-step (floats 4*(tid&7) .. +3).
+template <int WM, int WN, class ALoader, class BLoader>
+__device__ __forceinline__ void gemm_mainloop(ALoader& al, BLoader& bl, int ksteps, float* lds,
+                                              f32x16 (&acc)[WM][WN]) {
+  using T = Tile<WM, WN>;
+  constexpr int BM = T::BM, BN = T::BN, NA = T::NA, NB = T::NB;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+
+  constexpr int BUF = (BM + BN) * LDS_STRIDE;   // floats per LDS buffer: A rows then B rows
+  constexpr int OFFB = BM * LDS_STRIDE;
+
+  // staging coordinates
+  const int st_row = tid >> 3;
+  const int st_off = st_row * LDS_STRIDE + (tid & 7) * 4;
+  // fragment read coordinates
+  const int fr_off = (lane & 31) * LDS_STRIDE + 8 * (lane >> 5);
+
+  f32x4 ra[NA], rb[NB];
+  al.load(0, ra);
+  bl.load(0, rb);
+#pragma unroll
+  for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(lds + st_off + i * 32 * LDS_STRIDE) = ra[i];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(lds + OFFB + st_off + i * 32 * LDS_STRIDE) = rb[i];
+  __syncthreads();
+
+  for (int ks = 0; ks < ksteps; ++ks) {
+    const int cur = ks & 1;
+    const bool more = (ks + 1 < ksteps);
+    if (more) {
+      al.load(ks + 1, ra);
+      bl.load(ks + 1, rb);
+    }
+    const float* pa = lds + cur * BUF + (wr * WM * 32) * LDS_STRIDE + fr_off;
+    const float* pb = lds + cur * BUF + OFFB + (wc * WN * 32) * LDS_STRIDE + fr_off;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      f32x4 fa[WM][2], fb[WN][2];
+#pragma unroll
+      for (int m = 0; m < WM; ++m) {
+        fa[m][0] = *reinterpret_cast<const f32x4*>(pa + m * 32 * LDS_STRIDE + 16 * s);
+        fa[m][1] = *reinterpret_cast<const f32x4*>(pa + m * 32 * LDS_STRIDE + 16 * s + 4);
+      }
+#pragma unroll
+      for (int n = 0; n < WN; ++n) {
+        fb[n][0] = *reinterpret_cast<const f32x4*>(pb + n * 32 * LDS_STRIDE + 16 * s);
+        fb[n][1] = *reinterpret_cast<const f32x4*>(pb + n * 32 * LDS_STRIDE + 16 * s + 4);
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+#pragma unroll
+        for (int m = 0; m < WM; ++m) {
+#pragma unroll
+          for (int n = 0; n < WN; ++n) {
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[m][t >> 2][t & 3], fb[n][t >> 2][t & 3],
+                                                             acc[m][n], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (more) {
+      float* wa = lds + (cur ^ 1) * BUF + st_off;
+      float* wb = lds + (cur ^ 1) * BUF + OFFB + st_off;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(wa + i * 32 * LDS_STRIDE) = ra[i];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(wb + i * 32 * LDS_STRIDE) = rb[i];
+    }
+    __syncthreads();
+  }
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// Buffer resource over [base, base + bytes): loads past the end return zeros, which is
+// how tile tails and the zero halo of a convolution are produced without branches.
+// Built from wave-uniform values only (kernel arguments / blockIdx), so hipcc keeps the
+// descriptor in SGPRs (cdna_hip_programming.md T20).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
+constexpr uint32_t OOB = 0xFFFFFFF0u;   // byte offset guaranteed past any descriptor's range
+
+// Row-major [rows][ld] matrix, K contiguous; rows >= nrows read as zero.  Used for packed
+// convolution weights ([Cout][Kpad]), the gallery, the probes and the ArcMargin class
+// centres.  `base` points at the tile's first row (block-uniform), so byte offsets stay
+// below 2^32 for any tile; ld is a multiple of 4 and K is padded to a multiple of BK.
+template <int N>
+struct RowLoader {
+  __amdgpu_buffer_rsrc_t rsrc;
+  uint32_t off0;   // byte offset of (row = tid>>3, k = 4*(tid&7)) inside the tile
+  uint32_t ldb;    // row pitch in bytes
+  __device__ __forceinline__ RowLoader(const float* tile_base, int64_t rows_left, int ld) {
+    const int tid = threadIdx.x;
+    const int64_t rows = rows_left < 32 * N ? rows_left : 32 * N;
+    rsrc = make_rsrc(tile_base, (uint32_t)(rows * ld * 4));
+    ldb = (uint32_t)ld * 4u;
+    off0 = (uint32_t)(tid >> 3) * ldb + (uint32_t)(tid & 7) * 16u;
+  }
+  __device__ __forceinline__ void load(int kstep, f32x4 (&r)[N]) const {
+    const uint32_t o = off0 + (uint32_t)kstep * (BK * 4);
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = buf_load4(rsrc, o + (uint32_t)i * 32u * ldb);
+  }
+};
+
+}  // namespace dif

@@ -1,0 +1,92 @@
+"""1:N gallery match ("one shot" identification) on the MI355X.
+
+The reference's oneshot.py is an unfinished Omniglot stub with no distance code
+(deep_insight_face/oneshot.py:8 "TODO: FIX THIS MODULE"); north_star houses the
+pairwise cosine-distance gallery match under this module name.  Semantics: for every
+probe row q, ``np.argmin(evaluation.utility.distance(q[None, :], gallery, metric))``
+(evaluation/utility.py:52-66 broadcast over the gallery; first minimum wins).
+"""
+import ctypes
+
+import torch
+
+from . import _native as N
+
+
+class Gallery:
+    """Device-resident gallery of enrolled embeddings, [G, d] float32.
+
+    One instance per process/GPU.  With ``index_base`` the rows are a shard of a larger
+    gallery (see deep_insight_face.parallel.ShardedGallery)."""
+
+    def __init__(self, embeddings=None, emd_size=None, index_base=0):
+        self._h = ctypes.c_void_p()
+        self._dev = N.require_device()
+        if embeddings is not None and emd_size is None:
+            emd_size = int(embeddings.shape[1])
+        if emd_size is None:
+            raise ValueError('Gallery needs embeddings or emd_size')
+        N.check(N.lib.dif_gallery_create(ctypes.byref(self._h), int(emd_size)), ValueError)
+        self.emd_size = int(emd_size)
+        if embeddings is not None:
+            self.set(embeddings, index_base)
+
+    def set(self, embeddings, index_base=0):
+        g, _ = N.to_device_f32(embeddings, self._dev)
+        if g.dim() != 2 or g.shape[1] != self.emd_size:
+            raise ValueError('gallery must be [G, %d], got %s' % (self.emd_size, tuple(g.shape)))
+        N.check(N.lib.dif_gallery_set(self._h, N.ptr(g), g.shape[0], int(index_base), N.stream_ptr()))
+        torch.cuda.current_stream().synchronize()   # g may be a temporary: the copy must have landed
+
+    def __len__(self):
+        return int(N.lib.dif_gallery_size(self._h))
+
+    def match(self, probes, distance_metric=1, return_key=False):
+        """-> (idx[B] int64, dist[B] float32) [, key[B]]; NumPy in -> NumPy out."""
+        if distance_metric not in (0, 1):
+            raise RuntimeError('Undefined distance metric %d' % distance_metric)
+        p, was_np = N.to_device_f32(probes, self._dev)
+        if p.dim() == 1:
+            p = p[None, :]
+        if p.dim() != 2 or p.shape[1] != self.emd_size:
+            raise ValueError('probes must be [B, %d], got %s' % (self.emd_size, tuple(p.shape)))
+        B = p.shape[0]
+        idx = torch.empty((B,), dtype=torch.int64, device=self._dev)
+        dist = torch.empty((B,), dtype=torch.float32, device=self._dev)
+        key = torch.empty((B,), dtype=torch.float32, device=self._dev)
+        if B:
+            if len(self) == 0:
+                raise ValueError('attempt to get argmin of an empty sequence')   # what np.argmin raises
+            N.check(N.lib.dif_match(self._h, N.ptr(p), B, distance_metric, N.ptr(idx), N.ptr(dist),
+                                    N.ptr(key), N.stream_ptr()))
+        if was_np:
+            idx, dist, key = idx.cpu().numpy(), dist.cpu().numpy(), key.cpu().numpy()
+        return (idx, dist, key) if return_key else (idx, dist)
+
+    def close(self):
+        if self._h:
+            N.lib.dif_gallery_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def match(probes, gallery, distance_metric=1):
+    """One-call form: top-1 gallery index and distance for each probe row."""
+    g = gallery if isinstance(gallery, Gallery) else Gallery(gallery)
+    try:
+        return g.match(probes, distance_metric)
+    finally:
+        if g is not gallery:
+            g.close()
+
+
+def one_shot_clf(probe, gallery, distance_metric=1):
+    """Identify one face: index of the nearest enrolled embedding and its distance
+    (name kept from the reference stub, deep_insight_face/oneshot.py:110)."""
+    idx, dist = match(probe, gallery, distance_metric)
+    return int(idx[0]), float(dist[0])

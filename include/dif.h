@@ -1,0 +1,122 @@
+/* libdif -- C ABI of the MI355X-native embedding + match hot path.
+ *
+ * The reference (sandyz1000/deep-insight-face) has no FFI: its seam is a duck-typed
+ * Python protocol.  Each entry point below names the
+ * reference interface it stands behind (paths relative to the reference root).  The
+ * Python host side (deep-insight-face_amd/deep_insight_face/) binds these with ctypes
+ * and keeps the reference's call signatures; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; dif_last_error()
+ *     returns the message of the calling thread's last failure;
+ *   - pointers named *_dev are DEVICE pointers borrowed for the duration of the call
+ *     (stream-ordered: the work is enqueued on `stream`, a hipStream_t passed as
+ *     void*; NULL = the default stream); host pointers are named *_host;
+ *   - handles own their device memory (weights, gallery copy, workspaces) and are not
+ *     re-entrant: one handle per process/GPU, calls on one handle from one thread;
+ *   - there is NO CPU fallback: without a HIP device every compute entry point fails.
+ */
+#ifndef DIF_H
+#define DIF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DIF_VERSION 100
+
+/* distance metrics: evaluation/utility.py:52-66 */
+#define DIF_METRIC_SQL2 0   /* sum((a-b)^2, axis=1)                     utility.py:53-56 */
+#define DIF_METRIC_COSINE 1 /* arccos(a.b / (|a||b|)) / pi              utility.py:57-62 */
+
+/* input layouts / dtypes accepted by dif_net_embed */
+#define DIF_LAYOUT_NHWC 0 /* the reference's layout (networks/inceptionv3.py:94,98) */
+#define DIF_LAYOUT_NCHW 1 /* north_star's torch-side layout */
+#define DIF_DTYPE_F32 0
+#define DIF_DTYPE_U8 1
+
+typedef struct dif_gallery dif_gallery;
+typedef struct dif_net dif_net;
+typedef struct dif_arcmargin dif_arcmargin;
+
+int dif_version(void);
+const char* dif_last_error(void);
+/* number of visible HIP devices (0 without a GPU); never fails */
+int dif_device_count(void);
+
+/* ------------------------------------------------------------------ distances
+ * Row-paired distance, out_dev[i] = d(e1[i], e2[i]); n1 or n2 may be 1 (NumPy
+ * broadcast of a single row, which is how a probe is compared with a whole gallery
+ * in the reference's terms).  Replaces evaluation/utility.py:52-66 `distance`
+ * (and its twin :174-188).  metric other than 0/1 fails like the reference's
+ * RuntimeError('Undefined distance metric %d'). */
+int dif_pairwise(const float* e1_dev, int64_t n1, const float* e2_dev, int64_t n2, int d, int metric,
+                 float* out_dev, void* stream);
+
+/* ------------------------------------------------------------------ gallery + 1:N match
+ * The reference has no 1:N entry point; the semantics are utility.distance broadcast
+ * over gallery rows + np.argmin (first minimum).  Housed Python-side under
+ * deep_insight_face.oneshot (north_star). */
+int dif_gallery_create(dif_gallery** out, int d);
+int dif_gallery_destroy(dif_gallery* g);
+/* copy `n` rows of `d` floats from device memory into the handle and precompute the
+ * per-row norms; index_base = global index of row 0 (gallery row-sharded over ranks) */
+int dif_gallery_set(dif_gallery* g, const float* rows_dev, int64_t n, int64_t index_base, void* stream);
+int64_t dif_gallery_size(const dif_gallery* g);
+/* top-1 search of n probes [n][d]: idx_out_dev[n] (int64 global index, first minimum),
+ * dist_out_dev[n] (float32 distance in the reference's formula), key_out_dev[n]
+ * (optional, may be NULL: monotone search key, comparable across gallery shards). */
+int dif_match(dif_gallery* g, const float* probes_dev, int n, int metric, int64_t* idx_out_dev,
+              float* dist_out_dev, float* key_out_dev, void* stream);
+/* merge R per-shard results laid out [R][n] (after an all-gather): lowest key, then
+ * lowest global index -- equals np.argmin over the concatenated gallery */
+int dif_match_merge(const float* keys_dev, const int64_t* idx_dev, const float* dist_dev, int R, int n,
+                    int64_t* idx_out_dev, float* dist_out_dev, void* stream);
+
+/* ------------------------------------------------------------------ embedding network
+ * Stands behind the Keras model object of the reference:
+ *   bottleneck_network(net, emd_size, input_shape)(default_model_ver)   networks/triplet.py:73-85
+ *   emd_model.predict_on_batch(x[N,H,W,3]) -> [N,emd]                    predictions.py:96,156; evaluation/evals.py:56
+ * arch: "resnet" (keras ResNet50V2, triplet.py:90-91), "iresnet50", "iresnet100"
+ * head: "v1" (triplet.py:102-117), "v2" (GDC + L2-norm, triplet.py:119-141),
+ *       "v3" (bare backbone, triplet.py:143-146); ignored for iresnet*. */
+int dif_net_create(dif_net** out, const char* arch, const char* head, int emd_size, int in_h, int in_w);
+int dif_net_destroy(dif_net* net);
+/* parameter table, in model order.  Shapes are Keras conventions: conv kernels
+ * [kh,kw,cin,cout], depthwise [kh,kw,c,1], dense [in,out], vectors [c]. */
+int dif_net_param_count(const dif_net* net);
+int dif_net_param_info(const dif_net* net, int i, const char** name, int* ndim, int64_t shape[4]);
+/* copy one parameter from HOST memory (model.load_weights, api.py:87) */
+int dif_net_set_param(dif_net* net, const char* name, const float* data_host, int64_t count);
+/* read one parameter back to HOST memory (model.save_weights, networks/inceptionv3.py:86-88) */
+int dif_net_get_param(const dif_net* net, const char* name, float* data_host, int64_t count);
+/* input transform applied while converting to the internal NHWC4 f32 layout:
+ * y[c] = x[bgr ? 2-c : c] * scale + bias[c]   (predictions.py:94,154 `* rescale`;
+ * predictions.py:95 keras vgg16 preprocess_input = BGR swap + mean subtraction) */
+int dif_net_set_input_transform(dif_net* net, float scale, const float bias[3], int bgr);
+/* pack weights for the kernels, upload, and size the activation workspace */
+int dif_net_finalize(dif_net* net, int max_batch);
+int dif_net_output_dim(const dif_net* net, int64_t shape[3]); /* {emd,1,1} or {C,H,W} for v3 */
+/* forward n <= max_batch images; x_dev is [n,H,W,3] (NHWC) or [n,3,H,W] (NCHW), f32 or u8;
+ * out_dev is [n][emd] float32 (v3: [n,H,W,C] NHWC). */
+int dif_net_embed(dif_net* net, const void* x_dev, int n, int layout, int dtype, float* out_dev, void* stream);
+/* algorithmic FLOPs of one forward per image (2 * MACs of every conv/dense), for rooflines */
+double dif_net_flops_per_image(const dif_net* net);
+/* debugging / profiling aid: number of kernel launches per forward */
+int dif_net_launch_count(const dif_net* net);
+
+/* ------------------------------------------------------------------ ArcMargin logits
+ * Not in the reference (north_star only; ArcFace, Deng et al. 2019):
+ * logits = s * cos(theta + m * onehot(label)); labels_dev NULL -> s * cos(theta). */
+int dif_arcmargin_create(dif_arcmargin** out, int d, int64_t n_classes, float s, float m);
+int dif_arcmargin_destroy(dif_arcmargin* a);
+int dif_arcmargin_set_weight(dif_arcmargin* a, const float* w_dev, void* stream); /* [C][d], rows normalised internally */
+int dif_arcmargin_logits(dif_arcmargin* a, const float* emb_dev, const int64_t* labels_dev, int n,
+                         float* logits_dev, void* stream); /* [n][C] */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIF_H */

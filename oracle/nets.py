@@ -1,0 +1,330 @@
+"""NumPy restatement of the embedding forward pass.  TEST INFRASTRUCTURE ONLY
+(see oracle/__init__.py).  **PARITY UNPINNED** for everything in this file:
+
+  * ResNet50V2 is ``tensorflow.keras.applications.ResNet50V2(include_top=False)``
+    as selected by ``deep_insight_face/networks/triplet.py:87-91`` /
+    ``networks/siamese.py:81-85`` -- third-party, un-vendored, no pinned version
+    (requirements.txt is empty); TensorFlow is not installed here.  The layer
+    table below restates the public Keras definition.
+  * The heads follow the in-repo builders line by line:
+    GDC head  = ``networks/triplet.py:119-141`` (build_models_v2),
+    small head = ``networks/triplet.py:102-117`` / ``networks/siamese.py:91-105``
+    (build_models_v1).
+  * IResNet-50/100 and ArcMargin are absent from the reference; they follow the
+    public ArcFace definitions.
+
+All tensors are NHWC ("channels_last", as the reference: ``networks/inceptionv3.py:98``)
+and are computed in ``dtype`` (float32 like the reference; float64 is offered
+as an arbiter when two float32 implementations disagree in the last bits).
+Convolution kernels are Keras HWIO ``[kh, kw, cin, cout]``; dense kernels are
+``[in, out]``.
+"""
+import math
+
+import numpy as np
+
+BN_EPS_RESNET = 1.001e-5   # keras.applications resnet BN epsilon
+BN_EPS_KERAS = 1e-3        # keras.layers.BatchNormalization default (head: triplet.py:127,130)
+BN_EPS_IRESNET = 1e-5      # ArcFace IResNet (torch BatchNorm default)
+
+
+# --------------------------------------------------------------------------- layers
+def conv2d(x, w, bias=None, stride=1, pad=(0, 0, 0, 0)):
+    """x [N,H,W,C], w [kh,kw,C,O]; pad = (top, bottom, left, right) explicit zeros.
+    im2col + one matmul per call."""
+    kh, kw, cin, cout = w.shape
+    n, h, wd, c = x.shape
+    assert c == cin, (x.shape, w.shape)
+    if any(pad):
+        x = np.pad(x, ((0, 0), (pad[0], pad[1]), (pad[2], pad[3]), (0, 0)))
+    hp, wp = x.shape[1], x.shape[2]
+    ho = (hp - kh) // stride + 1
+    wo = (wp - kw) // stride + 1
+    if kh == 1 and kw == 1:
+        cols = x[:, ::stride, ::stride, :][:, :ho, :wo, :].reshape(n * ho * wo, cin)
+    else:
+        s = x.strides
+        win = np.lib.stride_tricks.as_strided(
+            x, shape=(n, ho, wo, kh, kw, cin),
+            strides=(s[0], s[1] * stride, s[2] * stride, s[1], s[2], s[3]), writeable=False)
+        cols = win.reshape(n * ho * wo, kh * kw * cin)
+    y = cols @ w.reshape(kh * kw * cin, cout)
+    if bias is not None:
+        y = y + bias
+    return y.reshape(n, ho, wo, cout)
+
+
+def same_pad(size, k, stride):
+    """TensorFlow 'SAME' padding for one axis -> (before, after)."""
+    out = -(-size // stride)
+    total = max((out - 1) * stride + k - size, 0)
+    return total // 2, total - total // 2
+
+
+def batchnorm(x, p, prefix, eps):
+    """Inference BN the way Keras evaluates it: x * (gamma * rsqrt(var+eps)) +
+    (beta - mean * gamma * rsqrt(var+eps))."""
+    g = p[prefix + '/gamma']
+    b = p[prefix + '/beta']
+    m = p[prefix + '/moving_mean']
+    v = p[prefix + '/moving_variance']
+    scale = (g / np.sqrt(v + np.asarray(eps, dtype=x.dtype))).astype(x.dtype)
+    shift = (b - m * scale).astype(x.dtype)
+    return x * scale + shift
+
+
+def relu(x):
+    return np.maximum(x, 0)
+
+
+def prelu(x, alpha):
+    return np.where(x >= 0, x, x * alpha)
+
+
+def maxpool(x, k, stride, pad=(0, 0, 0, 0), pad_value=0.0):
+    """Max pooling.  Keras ResNet50V2 pads with an explicit ZeroPadding2D before a
+    VALID pool (pad_value 0); 'same' pools pad with -inf."""
+    if any(pad):
+        x = np.pad(x, ((0, 0), (pad[0], pad[1]), (pad[2], pad[3]), (0, 0)), constant_values=pad_value)
+    n, h, w, c = x.shape
+    ho = (h - k) // stride + 1
+    wo = (w - k) // stride + 1
+    s = x.strides
+    win = np.lib.stride_tricks.as_strided(
+        x, shape=(n, ho, wo, k, k, c),
+        strides=(s[0], s[1] * stride, s[2] * stride, s[1], s[2], s[3]), writeable=False)
+    return win.max(axis=(3, 4))
+
+
+def l2_normalize(x, eps=1e-12):
+    """tf.nn.l2_normalize(axis=1): x * rsqrt(max(sum(x^2), eps)).  triplet.py:138."""
+    ss = np.sum(x * x, axis=1, keepdims=True)
+    return x / np.sqrt(np.maximum(ss, np.asarray(eps, dtype=x.dtype)))
+
+
+# --------------------------------------------------------------------------- ResNet50V2
+RESNET50V2_STACKS = ((64, 3, 2), (128, 4, 2), (256, 6, 2), (512, 3, 1))  # (filters, blocks, stride on last)
+
+
+def _block_v2(x, p, name, filters, stride, conv_shortcut):
+    pre = relu(batchnorm(x, p, name + '_preact_bn', BN_EPS_RESNET))
+    if conv_shortcut:
+        sc = conv2d(pre, p[name + '_0_conv/kernel'], p[name + '_0_conv/bias'], stride=stride)
+    elif stride > 1:
+        sc = x[:, ::stride, ::stride, :]            # MaxPooling2D(1, strides=stride)
+    else:
+        sc = x
+    y = conv2d(pre, p[name + '_1_conv/kernel'])
+    y = relu(batchnorm(y, p, name + '_1_bn', BN_EPS_RESNET))
+    y = conv2d(y, p[name + '_2_conv/kernel'], stride=stride, pad=(1, 1, 1, 1))
+    y = relu(batchnorm(y, p, name + '_2_bn', BN_EPS_RESNET))
+    y = conv2d(y, p[name + '_3_conv/kernel'], p[name + '_3_conv/bias'])
+    return sc + y
+
+
+def resnet50v2(x, p):
+    """[N,H,W,3] -> [N,H/32 (ceil),W/32,2048] (4x4x2048 at 112 px)."""
+    y = conv2d(x, p['conv1_conv/kernel'], p['conv1_conv/bias'], stride=2, pad=(3, 3, 3, 3))
+    y = maxpool(y, 3, 2, pad=(1, 1, 1, 1))
+    for si, (filters, blocks, stride1) in enumerate(RESNET50V2_STACKS):
+        s = 'conv%d' % (si + 2)
+        y = _block_v2(y, p, s + '_block1', filters, 1, True)
+        for b in range(2, blocks):
+            y = _block_v2(y, p, s + '_block%d' % b, filters, 1, False)
+        y = _block_v2(y, p, s + '_block%d' % blocks, filters, stride1, False)
+    return relu(batchnorm(y, p, 'post_bn', BN_EPS_RESNET))
+
+
+def resnet50v2_spec(in_ch=3):
+    spec = [('conv1_conv/kernel', (7, 7, in_ch, 64)), ('conv1_conv/bias', (64,))]
+    cin = 64
+
+    def bn(name, c):
+        return [(name + '/' + k, (c,)) for k in ('gamma', 'beta', 'moving_mean', 'moving_variance')]
+
+    for si, (f, blocks, _) in enumerate(RESNET50V2_STACKS):
+        s = 'conv%d' % (si + 2)
+        for b in range(1, blocks + 1):
+            n = '%s_block%d' % (s, b)
+            spec += bn(n + '_preact_bn', cin)
+            if b == 1:
+                spec += [(n + '_0_conv/kernel', (1, 1, cin, 4 * f)), (n + '_0_conv/bias', (4 * f,))]
+            spec += [(n + '_1_conv/kernel', (1, 1, cin, f))] + bn(n + '_1_bn', f)
+            spec += [(n + '_2_conv/kernel', (3, 3, f, f))] + bn(n + '_2_bn', f)
+            spec += [(n + '_3_conv/kernel', (1, 1, f, 4 * f)), (n + '_3_conv/bias', (4 * f,))]
+            cin = 4 * f
+    spec += bn('post_bn', cin)
+    return spec
+
+
+# --------------------------------------------------------------------------- heads
+def head_gdc(feat, p, emd):
+    """build_models_v2, deep_insight_face/networks/triplet.py:119-141:
+    Conv1x1(512,no bias) -> BN -> PReLU(shared_axes=[1,2]) -> DepthwiseConv2D(kernel=H)
+    -> BN -> Conv1x1(emd,no bias) -> [Dropout = identity] -> Flatten ->
+    Dense(emd,no bias) -> l2_normalize(axis=1)."""
+    y = conv2d(feat, p['head_conv/kernel'])
+    y = batchnorm(y, p, 'head_bn1', BN_EPS_KERAS)
+    y = prelu(y, p['head_prelu/alpha'])
+    dw = p['head_dw/depthwise_kernel']                 # [H, W, 512, 1], kernel = full extent
+    assert dw.shape[0] == y.shape[1] and dw.shape[1] == y.shape[2], (dw.shape, y.shape)
+    y = np.einsum('nhwc,hwc->nc', y, dw[..., 0])[:, None, None, :]
+    y = batchnorm(y, p, 'head_bn2', BN_EPS_KERAS)
+    y = conv2d(y, p['head_pw/kernel'])
+    y = y.reshape(y.shape[0], -1)
+    y = y @ p['head_dense/kernel']
+    return l2_normalize(y)
+
+
+def head_gdc_spec(cin, hw, emd):
+    def bn(name, c):
+        return [(name + '/' + k, (c,)) for k in ('gamma', 'beta', 'moving_mean', 'moving_variance')]
+    return ([('head_conv/kernel', (1, 1, cin, 512))] + bn('head_bn1', 512) +
+            [('head_prelu/alpha', (512,)), ('head_dw/depthwise_kernel', (hw, hw, 512, 1))] +
+            bn('head_bn2', 512) +
+            [('head_pw/kernel', (1, 1, 512, emd)), ('head_dense/kernel', (emd, emd))])
+
+
+def head_v1(feat, p, emd):
+    """build_models_v1, deep_insight_face/networks/triplet.py:102-117:
+    Conv2x2(64,same,relu) -> MaxPool2 -> Conv2x2(32,same,relu) -> MaxPool2 ->
+    Flatten -> Dense(emd, bias).  No L2-normalise (commented out at :113)."""
+    def same(x, k):
+        t, b = same_pad(x.shape[1], k, 1)
+        l, r = same_pad(x.shape[2], k, 1)
+        return (t, b, l, r)
+    y = relu(conv2d(feat, p['v1_conv1/kernel'], p['v1_conv1/bias'], pad=same(feat, 2)))
+    y = maxpool(y, 2, 2)
+    y = relu(conv2d(y, p['v1_conv2/kernel'], p['v1_conv2/bias'], pad=same(y, 2)))
+    y = maxpool(y, 2, 2)
+    y = y.reshape(y.shape[0], -1)
+    return y @ p['embeddings/kernel'] + p['embeddings/bias']
+
+
+def head_v1_spec(cin, hw, emd):
+    h2 = (hw // 2) // 2
+    return [('v1_conv1/kernel', (2, 2, cin, 64)), ('v1_conv1/bias', (64,)),
+            ('v1_conv2/kernel', (2, 2, 64, 32)), ('v1_conv2/bias', (32,)),
+            ('embeddings/kernel', (h2 * h2 * 32, emd)), ('embeddings/bias', (emd,))]
+
+
+# --------------------------------------------------------------------------- IResNet
+IRESNET_LAYERS = {'iresnet50': (3, 4, 14, 3), 'iresnet100': (3, 13, 30, 3)}
+IRESNET_WIDTHS = (64, 128, 256, 512)
+
+
+def _iblock(x, p, name, stride, downsample):
+    y = batchnorm(x, p, name + '_bn1', BN_EPS_IRESNET)
+    y = conv2d(y, p[name + '_conv1/kernel'], pad=(1, 1, 1, 1))
+    y = batchnorm(y, p, name + '_bn2', BN_EPS_IRESNET)
+    y = prelu(y, p[name + '_prelu/alpha'])
+    y = conv2d(y, p[name + '_conv2/kernel'], stride=stride, pad=(1, 1, 1, 1))
+    y = batchnorm(y, p, name + '_bn3', BN_EPS_IRESNET)
+    if downsample:
+        sc = conv2d(x, p[name + '_down_conv/kernel'], stride=stride)
+        sc = batchnorm(sc, p, name + '_down_bn', BN_EPS_IRESNET)
+    else:
+        sc = x
+    return y + sc
+
+
+def iresnet(x, p, arch='iresnet100'):
+    """[N,112,112,3] -> unit-norm [N,512].  Public ArcFace IResNet: stem
+    Conv3x3(64)-BN-PReLU, 4 stages of IBasicBlock (each stage stride 2, 1x1
+    downsample on its first block), BN -> flatten (channel-major, as the NCHW
+    original) -> FC 512 -> BN1d, then L2-normalise."""
+    y = conv2d(x, p['conv1/kernel'], pad=(1, 1, 1, 1))
+    y = batchnorm(y, p, 'bn1', BN_EPS_IRESNET)
+    y = prelu(y, p['prelu/alpha'])
+    for li, nblk in enumerate(IRESNET_LAYERS[arch]):
+        for b in range(nblk):
+            y = _iblock(y, p, 'layer%d_%d' % (li + 1, b), 2 if b == 0 else 1, b == 0)
+    y = batchnorm(y, p, 'bn2', BN_EPS_IRESNET)
+    n = y.shape[0]
+    flat = np.transpose(y, (0, 3, 1, 2)).reshape(n, -1)          # c*HW + h*W + w
+    y = flat @ p['fc/kernel'] + p['fc/bias']
+    y = batchnorm(y, p, 'features', BN_EPS_IRESNET)
+    return l2_normalize(y)
+
+
+def iresnet_spec(arch='iresnet100', in_ch=3, emd=512, final_hw=7):
+    def bn(name, c):
+        return [(name + '/' + k, (c,)) for k in ('gamma', 'beta', 'moving_mean', 'moving_variance')]
+    spec = [('conv1/kernel', (3, 3, in_ch, 64))] + bn('bn1', 64) + [('prelu/alpha', (64,))]
+    cin = 64
+    for li, nblk in enumerate(IRESNET_LAYERS[arch]):
+        cout = IRESNET_WIDTHS[li]
+        for b in range(nblk):
+            n = 'layer%d_%d' % (li + 1, b)
+            spec += bn(n + '_bn1', cin) + [(n + '_conv1/kernel', (3, 3, cin, cout))]
+            spec += bn(n + '_bn2', cout) + [(n + '_prelu/alpha', (cout,))]
+            spec += [(n + '_conv2/kernel', (3, 3, cout, cout))] + bn(n + '_bn3', cout)
+            if b == 0:
+                spec += [(n + '_down_conv/kernel', (1, 1, cin, cout))] + bn(n + '_down_bn', cout)
+            cin = cout
+    spec += bn('bn2', 512) + [('fc/kernel', (512 * final_hw * final_hw, emd)), ('fc/bias', (emd,))]
+    spec += bn('features', emd)
+    return spec
+
+
+# --------------------------------------------------------------------------- ArcMargin
+def arcmargin_logits(emb, weight, labels=None, s=64.0, m=0.5):
+    """ArcFace (Deng et al. 2019) additive angular margin head; absent from the
+    reference.  cos = e_hat . w_hat; for the label class
+    phi = cos(theta + m) guarded by the usual threshold (cos > cos(pi-m) else
+    cos - sin(pi-m)*m); logits = s * (onehot*phi + (1-onehot)*cos).
+    ``labels`` None (inference) -> s * cos."""
+    e = emb / np.sqrt(np.maximum(np.sum(emb * emb, axis=1, keepdims=True), 1e-12)).astype(emb.dtype)
+    w = weight / np.sqrt(np.maximum(np.sum(weight * weight, axis=1, keepdims=True), 1e-12)).astype(weight.dtype)
+    cos = e @ w.T
+    if labels is None:
+        return (cos * np.asarray(s, dtype=cos.dtype))
+    cm, sm = math.cos(m), math.sin(m)
+    th, mm = math.cos(math.pi - m), math.sin(math.pi - m) * m
+    rows = np.arange(emb.shape[0])
+    c = cos[rows, labels]
+    sine = np.sqrt(np.clip(1.0 - c * c, 0.0, 1.0))
+    phi = c * cm - sine * sm
+    phi = np.where(c > th, phi, c - mm)
+    out = cos.copy()
+    out[rows, labels] = phi
+    return (out * np.asarray(s, dtype=cos.dtype)).astype(cos.dtype)
+
+
+# --------------------------------------------------------------------------- whole models
+def model_spec(arch, emd=512, input_hw=112, head='v2'):
+    """Ordered (name, shape) list for a full embedding model."""
+    if arch == 'resnet':
+        hw = input_hw
+        for _ in range(2):
+            hw = -(-hw // 2)
+        for (_, _, s) in RESNET50V2_STACKS:
+            if s == 2:
+                hw = -(-hw // 2)
+        spec = resnet50v2_spec()
+        if head == 'v2':
+            spec += head_gdc_spec(2048, hw, emd)
+        elif head == 'v1':
+            spec += head_v1_spec(2048, hw, emd)
+        return spec
+    if arch in IRESNET_LAYERS:
+        return iresnet_spec(arch, emd=emd, final_hw=input_hw // 16)
+    raise ValueError(arch)
+
+
+def embed(x, p, arch, emd=512, head='v2'):
+    """x: [N,H,W,3] already scaled (predictions.py:154 multiplies by 1/255)."""
+    if arch == 'resnet':
+        f = resnet50v2(x, p)
+        if head == 'v2':
+            return head_gdc(f, p, emd)
+        if head == 'v1':
+            return head_v1(f, p, emd)
+        if head == 'v3':
+            return f
+        raise ValueError(head)
+    return iresnet(x, p, arch)
+
+
+def cast_params(p, dtype):
+    return {k: np.asarray(v, dtype=dtype) for k, v in p.items()}
