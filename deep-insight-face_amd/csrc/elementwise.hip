@@ -1,0 +1,165 @@
+// Memory-bound layer kernels around the convolutions: input conversion, max pooling,
+// the GDC head's full-extent depthwise convolution, row-wise L2 normalisation.
+// All NHWC; channel runs are read/written as float4 (16 B per lane).
+#include "ops.hpp"
+#include "dif_internal.hpp"
+#include "../../include/dif.h"
+
+namespace dif {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------- input conversion
+// predictions.py:94,154: `cv2.resize(...) * rescale`; predictions.py:95: keras vgg16
+// preprocess_input (BGR swap + per-channel mean subtraction) for the siamese path.
+__global__ __launch_bounds__(256) void input_convert_kernel(const InputArgs a) {
+  const int64_t npix = (int64_t)a.N * a.H * a.W;
+  const int64_t HW = (int64_t)a.H * a.W;
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256) {
+    float v[3];
+    if (a.layout == DIF_LAYOUT_NHWC) {
+      if (a.dtype == DIF_DTYPE_U8) {
+        const uint8_t* s = static_cast<const uint8_t*>(a.x) + p * 3;
+        v[0] = s[0]; v[1] = s[1]; v[2] = s[2];
+      } else {
+        const float* s = static_cast<const float*>(a.x) + p * 3;
+        v[0] = s[0]; v[1] = s[1]; v[2] = s[2];
+      }
+    } else {
+      const int64_t n = p / HW, r = p - n * HW;
+      if (a.dtype == DIF_DTYPE_U8) {
+        const uint8_t* s = static_cast<const uint8_t*>(a.x) + n * 3 * HW + r;
+        v[0] = s[0]; v[1] = s[HW]; v[2] = s[2 * HW];
+      } else {
+        const float* s = static_cast<const float*>(a.x) + n * 3 * HW + r;
+        v[0] = s[0]; v[1] = s[HW]; v[2] = s[2 * HW];
+      }
+    }
+    f32x4 o;
+    o[0] = (a.bgr ? v[2] : v[0]) * a.scale + a.bias[0];
+    o[1] = v[1] * a.scale + a.bias[1];
+    o[2] = (a.bgr ? v[0] : v[2]) * a.scale + a.bias[2];
+    o[3] = 0.f;
+    *reinterpret_cast<f32x4*>(a.y + p * 4) = o;
+  }
+}
+
+int input_convert_run(const InputArgs& a, hipStream_t st) {
+  const int64_t npix = (int64_t)a.N * a.H * a.W;
+  if (npix == 0) return 0;
+  int64_t blocks = (npix + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(input_convert_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  DIF_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- max pooling
+__global__ __launch_bounds__(256) void maxpool_kernel(const PoolArgs a) {
+  const int C4 = a.C / 4;
+  const int64_t total = (int64_t)a.N * a.Ho * a.Wo * C4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
+    int64_t p = i / C4;
+    const int wo = (int)(p % a.Wo);
+    p /= a.Wo;
+    const int ho = (int)(p % a.Ho);
+    const int64_t n = p / a.Ho;
+    const float lo = -__builtin_inff();
+    f32x4 m = {lo, lo, lo, lo};
+    bool padded = false;
+    for (int kh = 0; kh < a.k; ++kh) {
+      const int hi = ho * a.stride - a.pad_t + kh;
+      for (int kw = 0; kw < a.k; ++kw) {
+        const int wi = wo * a.stride - a.pad_l + kw;
+        if ((unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(a.x + ((n * a.H + hi) * a.W + wi) * a.C + c4 * 4);
+          m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+        } else {
+          padded = true;
+        }
+      }
+    }
+    if (padded && a.zero_pad) {
+      m[0] = fmaxf(m[0], 0.f); m[1] = fmaxf(m[1], 0.f); m[2] = fmaxf(m[2], 0.f); m[3] = fmaxf(m[3], 0.f);
+    }
+    const int64_t o = ((n * a.Ho + ho) * a.Wo + wo) * a.C + c4 * 4;
+    *reinterpret_cast<f32x4*>(a.y + o) = m;
+    if (a.y2) {
+      const f32x4 s = a.scale2 ? *reinterpret_cast<const f32x4*>(a.scale2 + c4 * 4) : f32x4{1.f, 1.f, 1.f, 1.f};
+      const f32x4 t = a.shift2 ? *reinterpret_cast<const f32x4*>(a.shift2 + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 q;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        q[j] = fmaf(m[j], s[j], t[j]);
+        if (a.act2 == ACT_RELU) q[j] = fmaxf(q[j], 0.f);
+      }
+      *reinterpret_cast<f32x4*>(a.y2 + o) = q;
+    }
+  }
+}
+
+int maxpool_run(const PoolArgs& a, hipStream_t st) {
+  if (a.C % 4 != 0) return set_error("maxpool: C must be a multiple of 4 (got %d)", a.C);
+  const int64_t total = (int64_t)a.N * a.Ho * a.Wo * (a.C / 4);
+  if (total == 0) return 0;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  DIF_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- GDC depthwise (kernel = whole map) + BN
+// networks/triplet.py:129-130: DepthwiseConv2D(int(nn.shape[1]), depth_multiplier=1, use_bias=False) -> BN
+__global__ __launch_bounds__(256) void dwfull_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, float* __restrict__ y,
+                                                     int N, int HW, int C) {
+  const int64_t total = (int64_t)N * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const int64_t n = i / C;
+    float s = 0.f;
+    for (int p = 0; p < HW; ++p) s = fmaf(x[(n * HW + p) * C + c], w[(int64_t)p * C + c], s);
+    y[i] = fmaf(s, scale ? scale[c] : 1.f, shift ? shift[c] : 0.f);
+  }
+}
+
+int dwfull_run(const float* x, const float* w, const float* scale, const float* shift, float* y, int N, int HW,
+               int C, hipStream_t st) {
+  const int64_t total = (int64_t)N * C;
+  if (total == 0) return 0;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(dwfull_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, w, scale, shift, y, N, HW, C);
+  DIF_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- row-wise L2 normalisation
+// tf.nn.l2_normalize(axis=1) (networks/triplet.py:138): x * rsqrt(max(sum(x^2), 1e-12)); one wave per row.
+__global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x, float* __restrict__ y, int N,
+                                                     int D, float eps) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= N) return;
+  float s = 0.f;
+  for (int k = lane; k < D; k += 64) {
+    const float v = x[r * D + k];
+    s = fmaf(v, v, s);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float inv = 1.f / sqrtf(fmaxf(s, eps));
+  for (int k = lane; k < D; k += 64) y[r * D + k] = x[r * D + k] * inv;
+}
+
+int l2norm_run(const float* x, float* y, int N, int D, float eps, hipStream_t st) {
+  if (N == 0) return 0;
+  hipLaunchKernelGGL(l2norm_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, x, y, N, D, eps);
+  DIF_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace dif

@@ -1,0 +1,608 @@
+// Network construction (layer tables), weight packing and the launch sequence.
+//
+// Layer tables:
+//   "resnet"      keras.applications.ResNet50V2(include_top=False) as selected by
+//                 deep_insight_face/networks/triplet.py:90-91 (third-party; restated from
+//                 the public definition) followed by a head:
+//                   v1  triplet.py:102-117    v2 (GDC + L2-norm)  triplet.py:119-141
+//                   v3  triplet.py:143-146 (bare backbone)
+//   "iresnet50/100"  ArcFace IResNet (not in the reference).
+//
+// Fusion plan: every BatchNorm / bias / activation / shortcut add is folded into the
+// epilogue of the convolution that produces its input; the pre-activation BN of the NEXT
+// residual block is emitted as the producing convolution's second output.  A forward is
+// therefore convolutions + one max-pool + the tiny head kernels, nothing else.
+#include "net.hpp"
+
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "../../include/dif.h"
+#include "dif_internal.hpp"
+#include "gemm_core.hpp"
+
+namespace dif {
+
+static const float EPS_RESNET = 1.001e-5f;   // keras.applications.resnet BN epsilon
+static const float EPS_KERAS = 1e-3f;        // keras BatchNormalization default (triplet.py:127,130)
+static const float EPS_IRESNET = 1e-5f;      // torch BatchNorm default
+
+Net::~Net() { release_device(); }
+
+void Net::release_device() {
+  for (void* p : allocs) (void)hipFree(p);
+  allocs.clear();
+  bufs.clear();
+  finalized = false;
+}
+
+int Net::P(const std::string& name, std::vector<int64_t> shape) {
+  Param p;
+  p.name = name;
+  p.shape = shape;
+  params.push_back(p);
+  pindex[name] = (int)params.size() - 1;
+  return (int)params.size() - 1;
+}
+
+BNRef Net::BN(const std::string& prefix, int C, float eps) {
+  BNRef r;
+  r.gamma = P(prefix + "/gamma", {C});
+  r.beta = P(prefix + "/beta", {C});
+  r.mean = P(prefix + "/moving_mean", {C});
+  r.var = P(prefix + "/moving_variance", {C});
+  r.eps = eps;
+  return r;
+}
+
+int Net::T(int H, int W, int C) {
+  TensorDesc t;
+  t.H = H;
+  t.W = W;
+  t.C = C;
+  tensors.push_back(t);
+  return (int)tensors.size() - 1;
+}
+
+// Adds a convolution op.  `pad` is symmetric explicit zero padding (VALID on the padded
+// map, like Keras ZeroPadding2D + Conv2D); same_pad_even = TensorFlow 'SAME' for an even
+// kernel at stride 1 (pad 0 before, k-1 after).  Returns the y tensor (or -1 if !want_y).
+int Net::conv(const std::string& name, int x, int KH, int KW, int stride, int pad, int Cout, bool bias,
+              const BNRef& bn, int act, int alpha, int res, int res_stride, bool want_y, const BNRef& bn2,
+              int act2, int* y2_out, const std::string& wsuffix, bool same_pad_even) {
+  const TensorDesc xd = tensors[x];
+  Op op;
+  op.kind = OP_CONV;
+  op.name = name;
+  op.x = x;
+  op.KH = KH;
+  op.KW = KW;
+  op.stride = stride;
+  op.pad_t = op.pad_l = pad;
+  op.Cin = xd.C;
+  op.Cin_true = (x == input_tensor) ? 3 : xd.C;
+  op.Cout = Cout;
+  int Ho, Wo;
+  if (same_pad_even) {
+    Ho = xd.H;
+    Wo = xd.W;
+  } else {
+    Ho = (xd.H + 2 * pad - KH) / stride + 1;
+    Wo = (xd.W + 2 * pad - KW) / stride + 1;
+  }
+  if (wsuffix == "/kernel" && KH * KW * op.Cin_true > 0) {
+    // dense layers are registered by the caller with their own 2-D shape
+  }
+  op.w = P(name + wsuffix, {KH, KW, op.Cin_true, Cout});
+  if (bias) op.bias = P(name + "/bias", {Cout});
+  op.bn = bn;
+  op.act = act;
+  op.alpha = alpha;
+  op.res = res;
+  op.res_stride = res_stride;
+  op.bn2 = bn2;
+  op.act2 = act2;
+  op.macs = (double)Ho * Wo * KH * KW * op.Cin_true * Cout;
+  op.y = want_y ? T(Ho, Wo, Cout) : -1;
+  if (y2_out) {
+    op.y2 = T(Ho, Wo, Cout);
+    *y2_out = op.y2;
+  }
+  ops.push_back(op);
+  return op.y;
+}
+
+// ----------------------------------------------------------------------------- ResNet50V2 + heads
+int Net::build_resnet50v2() {
+  const BNRef none;
+  input_tensor = T(in_h, in_w, 4);
+  {
+    Op in;
+    in.kind = OP_INPUT;
+    in.name = "input";
+    in.y = input_tensor;
+    ops.push_back(in);
+  }
+  // conv1_pad(3) + conv1_conv 7x7/2 (bias); preact network: no BN/ReLU here
+  int t = conv("conv1_conv", input_tensor, 7, 7, 2, 3, 64, true, none, ACT_NONE, -1, -1, 1, true, none, ACT_NONE,
+               nullptr);
+  // pool1_pad(1) + MaxPool 3x3/2; second output = relu(conv2_block1_preact_bn(.))
+  static const int stacks[4][3] = {{64, 3, 2}, {128, 4, 2}, {256, 6, 2}, {512, 3, 1}};
+  // BN parameter tables must be registered in model order: do it lazily per block below,
+  // but the preact BN of a block is consumed by the PREVIOUS op's epilogue, so create it first.
+  int x, pre;
+  {
+    const TensorDesc td = tensors[t];
+    Op p;
+    p.kind = OP_MAXPOOL;
+    p.name = "pool1_pool";
+    p.x = t;
+    p.KH = p.KW = 3;
+    p.stride = 2;
+    p.pad_t = p.pad_l = 1;
+    p.zero_pad = 1;
+    p.Cin = p.Cout = td.C;
+    const int Ho = (td.H + 2 - 3) / 2 + 1, Wo = (td.W + 2 - 3) / 2 + 1;
+    p.bn2 = BN("conv2_block1_preact_bn", 64, EPS_RESNET);
+    p.act2 = ACT_RELU;
+    p.y = T(Ho, Wo, td.C);
+    p.y2 = T(Ho, Wo, td.C);
+    x = p.y;
+    pre = p.y2;
+    ops.push_back(p);
+  }
+  int cin = 64;
+  for (int s = 0; s < 4; ++s) {
+    const int f = stacks[s][0], nb = stacks[s][1], stride1 = stacks[s][2];
+    for (int b = 1; b <= nb; ++b) {
+      char nm[64];
+      snprintf(nm, sizeof(nm), "conv%d_block%d", s + 2, b);
+      const std::string n(nm);
+      const bool conv_shortcut = (b == 1);
+      const int stride = (b == nb) ? stride1 : 1;
+      int sc = -1;
+      if (conv_shortcut)
+        sc = conv(n + "_0_conv", pre, 1, 1, stride, 0, 4 * f, true, none, ACT_NONE, -1, -1, 1, true, none,
+                  ACT_NONE, nullptr);
+      const BNRef bn1 = BN(n + "_1_bn", f, EPS_RESNET);
+      // parameter order inside a block follows the oracle's spec: _1_conv kernel precedes _1_bn
+      // (order is cosmetic: parameters are addressed by name)
+      int y1 = conv(n + "_1_conv", pre, 1, 1, 1, 0, f, false, bn1, ACT_RELU, -1, -1, 1, true, none, ACT_NONE,
+                    nullptr);
+      const BNRef bn2 = BN(n + "_2_bn", f, EPS_RESNET);
+      int y2 = conv(n + "_2_conv", y1, 3, 3, stride, 1, f, false, bn2, ACT_RELU, -1, -1, 1, true, none, ACT_NONE,
+                    nullptr);
+      // next pre-activation BN (or post_bn after the very last block)
+      std::string next;
+      int next_c = 4 * f;
+      const bool last = (s == 3 && b == nb);
+      if (last)
+        next = "post_bn";
+      else if (b == nb)
+        snprintf(nm, sizeof(nm), "conv%d_block1_preact_bn", s + 3), next = nm;
+      else
+        snprintf(nm, sizeof(nm), "conv%d_block%d_preact_bn", s + 2, b + 1), next = nm;
+      const BNRef nbn = BN(next, next_c, EPS_RESNET);
+      int pre_next = -1;
+      const int res = conv_shortcut ? sc : x;
+      const int res_stride = conv_shortcut ? 1 : stride;   // MaxPooling2D(1, strides=stride) on the shortcut
+      int xn = conv(n + "_3_conv", y2, 1, 1, 1, 0, 4 * f, true, none, ACT_NONE, -1, res, res_stride, !last, nbn,
+                    ACT_RELU, &pre_next);
+      x = xn;
+      pre = pre_next;
+      cin = 4 * f;
+    }
+  }
+  (void)cin;
+  const int feat = pre;   // relu(post_bn(.)): [H/32, W/32, 2048]
+  const TensorDesc fd = tensors[feat];
+  if (head == "v3") {
+    output_tensor = feat;
+    return 0;
+  }
+  if (head == "v2") {
+    // triplet.py:126-128  Conv2D(512, 1, use_bias=False) -> BN -> PReLU(shared_axes=[1,2])
+    const BNRef hb1 = BN("head_bn1", 512, EPS_KERAS);
+    const int al = P("head_prelu/alpha", {512});
+    int h = conv("head_conv", feat, 1, 1, 1, 0, 512, false, hb1, ACT_PRELU, al, -1, 1, true, none, ACT_NONE,
+                 nullptr);
+    // triplet.py:129-130  DepthwiseConv2D(kernel = map size) -> BN
+    if (fd.H != fd.W) return set_error("GDC head needs a square feature map (got %dx%d)", fd.H, fd.W);
+    Op d;
+    d.kind = OP_DWFULL;
+    d.name = "head_dw";
+    d.x = h;
+    d.KH = fd.H;
+    d.KW = fd.W;
+    d.Cin = d.Cout = 512;
+    d.w = P("head_dw/depthwise_kernel", {fd.H, fd.W, 512, 1});
+    d.bn = BN("head_bn2", 512, EPS_KERAS);
+    d.y = T(1, 1, 512);
+    d.macs = (double)fd.H * fd.W * 512;
+    ops.push_back(d);
+    // triplet.py:131  Conv2D(emd, 1, use_bias=False); :133-134 Dropout = identity at inference
+    int e = conv("head_pw", d.y, 1, 1, 1, 0, emd, false, none, ACT_NONE, -1, -1, 1, true, none, ACT_NONE, nullptr);
+    // triplet.py:135-136  Flatten -> Dense(emd, use_bias=False)
+    int q = conv("head_dense", e, 1, 1, 1, 0, emd, false, none, ACT_NONE, -1, -1, 1, true, none, ACT_NONE, nullptr);
+    params[ops.back().w].shape = {emd, emd};
+    // triplet.py:138  l2_normalize(axis=1)
+    Op l;
+    l.kind = OP_L2NORM;
+    l.name = "norm_embedding";
+    l.x = q;
+    l.Cin = l.Cout = emd;
+    l.y = T(1, 1, emd);
+    ops.push_back(l);
+    output_tensor = l.y;
+    return 0;
+  }
+  if (head == "v1") {
+    // triplet.py:105-106  Conv2D(64, 2, 'same', relu) -> MaxPooling2D(2)
+    int a = conv("v1_conv1", feat, 2, 2, 1, 0, 64, true, none, ACT_RELU, -1, -1, 1, true, none, ACT_NONE, nullptr,
+                 "/kernel", true);
+    auto pool2 = [&](int src, const char* nm) {
+      const TensorDesc td = tensors[src];
+      Op p;
+      p.kind = OP_MAXPOOL;
+      p.name = nm;
+      p.x = src;
+      p.KH = p.KW = 2;
+      p.stride = 2;
+      p.Cin = p.Cout = td.C;
+      p.y = T(td.H / 2, td.W / 2, td.C);
+      ops.push_back(p);
+      return p.y;
+    };
+    int b = pool2(a, "v1_pool1");
+    if (tensors[b].H < 1) return set_error("v1 head: feature map too small");
+    // triplet.py:108-109
+    int c = conv("v1_conv2", b, 2, 2, 1, 0, 32, true, none, ACT_RELU, -1, -1, 1, true, none, ACT_NONE, nullptr,
+                 "/kernel", true);
+    int d = pool2(c, "v1_pool2");
+    const TensorDesc dd = tensors[d];
+    if (dd.H < 1 || dd.W < 1)
+      return set_error("v1 head: the second 2x2 pool leaves an empty map (input %dx%d)", in_h, in_w);
+    // triplet.py:111-112  Flatten -> Dense(emd): a VALID conv whose kernel is the whole map
+    int e = conv("embeddings", d, dd.H, dd.W, 1, 0, emd, true, none, ACT_NONE, -1, -1, 1, true, none, ACT_NONE,
+                 nullptr);
+    params[ops.back().w].shape = {(int64_t)dd.H * dd.W * dd.C, emd};
+    output_tensor = e;
+    return 0;
+  }
+  return set_error("unknown head '%s' (v1, v2, v3)", head.c_str());
+}
+
+// ----------------------------------------------------------------------------- IResNet
+int Net::build_iresnet(const int* layers) {
+  const BNRef none;
+  if (in_h != in_w || in_h % 16 != 0) return set_error("iresnet needs a square input divisible by 16");
+  input_tensor = T(in_h, in_w, 4);
+  {
+    Op in;
+    in.kind = OP_INPUT;
+    in.name = "input";
+    in.y = input_tensor;
+    ops.push_back(in);
+  }
+  static const int widths[4] = {64, 128, 256, 512};
+  const BNRef bn1 = BN("bn1", 64, EPS_IRESNET);
+  const int al0 = P("prelu/alpha", {64});
+  BNRef next_bn = BN("layer1_0_bn1", 64, EPS_IRESNET);
+  int xb = -1;
+  int x = conv("conv1", input_tensor, 3, 3, 1, 1, 64, false, bn1, ACT_PRELU, al0, -1, 1, true, next_bn, ACT_NONE,
+               &xb);
+  for (int li = 0; li < 4; ++li) {
+    const int cout = widths[li];
+    for (int b = 0; b < layers[li]; ++b) {
+      char nm[64];
+      snprintf(nm, sizeof(nm), "layer%d_%d", li + 1, b);
+      const std::string n(nm);
+      const int stride = (b == 0) ? 2 : 1;
+      const BNRef bn2 = BN(n + "_bn2", cout, EPS_IRESNET);
+      const int al = P(n + "_prelu/alpha", {cout});
+      int t1 = conv(n + "_conv1", xb, 3, 3, 1, 1, cout, false, bn2, ACT_PRELU, al, -1, 1, true, none, ACT_NONE,
+                    nullptr);
+      int res = x;
+      if (b == 0) {
+        const BNRef dbn = BN(n + "_down_bn", cout, EPS_IRESNET);
+        res = conv(n + "_down_conv", x, 1, 1, stride, 0, cout, false, dbn, ACT_NONE, -1, -1, 1, true, none,
+                   ACT_NONE, nullptr);
+      }
+      const BNRef bn3 = BN(n + "_bn3", cout, EPS_IRESNET);
+      const bool last = (li == 3 && b == layers[li] - 1);
+      std::string nxt;
+      int nc = cout;
+      if (last)
+        nxt = "bn2";
+      else if (b == layers[li] - 1)
+        snprintf(nm, sizeof(nm), "layer%d_0_bn1", li + 2), nxt = nm;
+      else
+        snprintf(nm, sizeof(nm), "layer%d_%d_bn1", li + 1, b + 1), nxt = nm;
+      next_bn = BN(nxt, nc, EPS_IRESNET);
+      int xbn = -1;
+      int xn = conv(n + "_conv2", t1, 3, 3, stride, 1, cout, false, bn3, ACT_NONE, -1, res, 1, !last, next_bn,
+                    ACT_NONE, &xbn);
+      x = xn;
+      xb = xbn;
+    }
+  }
+  const TensorDesc fd = tensors[xb];   // bn2 output, [H/16, W/16, 512]
+  const BNRef feat = BN("features", emd, EPS_IRESNET);
+  int e = conv("fc", xb, fd.H, fd.W, 1, 0, emd, true, feat, ACT_NONE, -1, -1, 1, true, none, ACT_NONE, nullptr);
+  ops.back().chw_flatten = true;       // the original flattens NCHW: rows are c*HW + h*W + w
+  params[ops.back().w].shape = {(int64_t)fd.H * fd.W * fd.C, emd};
+  Op l;
+  l.kind = OP_L2NORM;
+  l.name = "norm_embedding";
+  l.x = e;
+  l.Cin = l.Cout = emd;
+  l.y = T(1, 1, emd);
+  ops.push_back(l);
+  output_tensor = l.y;
+  return 0;
+}
+
+int Net::build() {
+  if (emd <= 0) return set_error("emd_size must be positive");
+  if (in_h < 32 || in_w < 32) return set_error("input must be at least 32x32");
+  if (arch == "resnet") return build_resnet50v2();
+  if (arch == "iresnet50") {
+    static const int l[4] = {3, 4, 14, 3};
+    return build_iresnet(l);
+  }
+  if (arch == "iresnet100") {
+    static const int l[4] = {3, 13, 30, 3};
+    return build_iresnet(l);
+  }
+  // the reference asserts net in ('mobilenet','resnet','vgg16') (triplet.py:77); only the
+  // ResNet path is on the hot path named by north_star
+  return set_error("Invalid bottleneck network '%s' (supported: resnet, iresnet50, iresnet100)", arch.c_str());
+}
+
+double Net::flops_per_image() const {
+  double m = 0;
+  for (const Op& op : ops) m += op.macs;
+  return 2.0 * m;
+}
+
+// ----------------------------------------------------------------------------- finalize
+static int upload(Net* net, const std::vector<float>& host, float** out) {
+  float* d = nullptr;
+  DIF_HIP(hipMalloc(&d, std::max<size_t>(host.size(), 1) * sizeof(float)));
+  net->allocs.push_back(d);
+  if (!host.empty()) DIF_HIP(hipMemcpy(d, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+  *out = d;
+  return 0;
+}
+
+// scale/shift of "(acc + bias) -> BN":  scale = gamma / sqrt(var + eps), shift = beta - mean*scale (+ bias*scale)
+static void fold(const Net* net, const BNRef& bn, int bias, int C, std::vector<float>* scale,
+                 std::vector<float>* shift) {
+  scale->clear();
+  shift->clear();
+  if (bn.valid()) {
+    const float* g = net->params[bn.gamma].data.data();
+    const float* b = net->params[bn.beta].data.data();
+    const float* m = net->params[bn.mean].data.data();
+    const float* v = net->params[bn.var].data.data();
+    scale->resize(C);
+    shift->resize(C);
+    for (int c = 0; c < C; ++c) {
+      const float s = g[c] / sqrtf(v[c] + bn.eps);
+      (*scale)[c] = s;
+      (*shift)[c] = b[c] - m[c] * s;
+    }
+    if (bias >= 0) {
+      const float* bb = net->params[bias].data.data();
+      for (int c = 0; c < C; ++c) (*shift)[c] += bb[c] * (*scale)[c];
+    }
+  } else if (bias >= 0) {
+    *shift = net->params[bias].data;
+  }
+}
+
+int Net::finalize(int mb) {
+  if (mb <= 0) return set_error("max_batch must be positive");
+  for (const Param& p : params)
+    if (!p.set) return set_error("parameter '%s' was never set", p.name.c_str());
+  release_device();
+  max_batch = mb;
+
+  // ---- weights and epilogue vectors
+  for (Op& op : ops) {
+    std::vector<float> scale, shift;
+    if (op.kind == OP_CONV) {
+      const int taps = op.KH * op.KW;
+      const int K = taps * op.Cin;
+      op.Kpad = (K + BK - 1) / BK * BK;
+      std::vector<float> packed((size_t)op.Cout * op.Kpad, 0.f);
+      const float* w = params[op.w].data.data();   // [taps][Cin_true][Cout] (HWIO) or CHW-flattened dense
+      for (int t = 0; t < taps; ++t)
+        for (int ci = 0; ci < op.Cin_true; ++ci) {
+          const int64_t src_row = op.chw_flatten ? ((int64_t)ci * taps + t) : ((int64_t)t * op.Cin_true + ci);
+          const float* src = w + src_row * op.Cout;
+          for (int co = 0; co < op.Cout; ++co) packed[(size_t)co * op.Kpad + (size_t)t * op.Cin + ci] = src[co];
+        }
+      if (upload(this, packed, &op.d_w)) return -1;
+      fold(this, op.bn, op.bias, op.Cout, &scale, &shift);
+      if (!scale.empty() && upload(this, scale, &op.d_scale)) return -1;
+      if (!shift.empty() && upload(this, shift, &op.d_shift)) return -1;
+      if (op.alpha >= 0 && upload(this, params[op.alpha].data, &op.d_alpha)) return -1;
+    } else if (op.kind == OP_DWFULL) {
+      if (upload(this, params[op.w].data, &op.d_w)) return -1;   // [H][W][C][1] == [HW][C]
+      fold(this, op.bn, -1, op.Cout, &scale, &shift);
+      if (!scale.empty() && upload(this, scale, &op.d_scale)) return -1;
+      if (!shift.empty() && upload(this, shift, &op.d_shift)) return -1;
+    }
+    if (op.y2 >= 0) {
+      fold(this, op.bn2, -1, op.Cout, &scale, &shift);
+      if (!scale.empty() && upload(this, scale, &op.d_scale2)) return -1;
+      if (!shift.empty() && upload(this, shift, &op.d_shift2)) return -1;
+      if (op.alpha2 >= 0 && upload(this, params[op.alpha2].data, &op.d_alpha2)) return -1;
+    }
+  }
+
+  // ---- activation buffers: liveness over the op list, first-fit reuse
+  for (TensorDesc& t : tensors) t.first_def = t.last_use = t.buf = -1;
+  for (int i = 0; i < (int)ops.size(); ++i) {
+    const Op& op = ops[i];
+    for (int t : {op.y, op.y2})
+      if (t >= 0 && tensors[t].first_def < 0) tensors[t].first_def = i;
+    for (int t : {op.x, op.res, op.y, op.y2})
+      if (t >= 0) tensors[t].last_use = std::max(tensors[t].last_use, i);
+  }
+  tensors[output_tensor].last_use = (int)ops.size();   // written straight into the caller's buffer
+  buf_elems.clear();
+  std::vector<int> free_list;
+  for (int i = 0; i < (int)ops.size(); ++i) {
+    const Op& op = ops[i];
+    for (int t : {op.y, op.y2}) {
+      if (t < 0 || t == output_tensor || tensors[t].buf >= 0) continue;
+      const int64_t need = tensors[t].elems();
+      int best = -1;
+      for (int k = 0; k < (int)free_list.size(); ++k) {
+        const int b = free_list[k];
+        if (buf_elems[b] >= need && (best < 0 || buf_elems[b] < buf_elems[free_list[best]])) best = k;
+      }
+      if (best >= 0) {
+        tensors[t].buf = free_list[best];
+        free_list.erase(free_list.begin() + best);
+      } else {
+        buf_elems.push_back(need);
+        tensors[t].buf = (int)buf_elems.size() - 1;
+      }
+    }
+    for (int t : {op.x, op.res, op.y, op.y2})
+      if (t >= 0 && t != output_tensor && tensors[t].last_use == i && tensors[t].buf >= 0) {
+        if (std::find(free_list.begin(), free_list.end(), tensors[t].buf) == free_list.end())
+          free_list.push_back(tensors[t].buf);
+      }
+  }
+  bufs.assign(buf_elems.size(), nullptr);
+  for (size_t b = 0; b < buf_elems.size(); ++b) {
+    float* d = nullptr;
+    DIF_HIP(hipMalloc(&d, (size_t)buf_elems[b] * max_batch * sizeof(float)));
+    allocs.push_back(d);
+    bufs[b] = d;
+  }
+  finalized = true;
+  return 0;
+}
+
+// ----------------------------------------------------------------------------- forward
+int Net::embed(const void* xin, int n, int layout, int dtype, float* out, hipStream_t st) {
+  if (!finalized) return set_error("dif_net_embed: call dif_net_finalize first");
+  if (n < 0 || n > max_batch) return set_error("dif_net_embed: batch %d outside [0, max_batch=%d]", n, max_batch);
+  if (n == 0) return 0;
+  if (!xin || !out) return set_error("dif_net_embed: null pointer");
+  if (layout != DIF_LAYOUT_NHWC && layout != DIF_LAYOUT_NCHW) return set_error("dif_net_embed: bad layout %d", layout);
+  if (dtype != DIF_DTYPE_F32 && dtype != DIF_DTYPE_U8) return set_error("dif_net_embed: bad dtype %d", dtype);
+  auto ptr = [&](int t) -> float* {
+    if (t < 0) return nullptr;
+    if (t == output_tensor) return out;
+    return bufs[tensors[t].buf];
+  };
+  for (const Op& op : ops) {
+    switch (op.kind) {
+      case OP_INPUT: {
+        InputArgs a;
+        a.x = xin;
+        a.y = ptr(op.y);
+        a.N = n;
+        a.H = in_h;
+        a.W = in_w;
+        a.layout = layout;
+        a.dtype = dtype;
+        a.scale = in_scale;
+        a.bias[0] = in_bias[0];
+        a.bias[1] = in_bias[1];
+        a.bias[2] = in_bias[2];
+        a.bgr = bgr;
+        if (input_convert_run(a, st)) return -1;
+        break;
+      }
+      case OP_CONV: {
+        const TensorDesc& xd = tensors[op.x];
+        const TensorDesc& yd = tensors[op.y >= 0 ? op.y : op.y2];
+        ConvArgs a;
+        memset(&a, 0, sizeof(a));
+        a.x = ptr(op.x);
+        a.w = op.d_w;
+        a.y = ptr(op.y);
+        a.y2 = ptr(op.y2);
+        a.scale = op.d_scale;
+        a.shift = op.d_shift;
+        a.alpha = op.d_alpha;
+        a.res = ptr(op.res);
+        a.scale2 = op.d_scale2;
+        a.shift2 = op.d_shift2;
+        a.alpha2 = op.d_alpha2;
+        a.N = n;
+        a.H = xd.H;
+        a.W = xd.W;
+        a.Cin = op.Cin;
+        a.Ho = yd.H;
+        a.Wo = yd.W;
+        a.Cout = op.Cout;
+        a.KH = op.KH;
+        a.KW = op.KW;
+        a.stride = op.stride;
+        a.pad_t = op.pad_t;
+        a.pad_l = op.pad_l;
+        a.Kpad = op.Kpad;
+        a.M = n * yd.H * yd.W;
+        a.act = op.act;
+        a.act2 = op.act2;
+        if (op.res >= 0) {
+          a.res_H = tensors[op.res].H;
+          a.res_W = tensors[op.res].W;
+          a.res_stride = op.res_stride;
+        } else {
+          a.res_H = yd.H;
+          a.res_W = yd.W;
+          a.res_stride = 1;
+        }
+        if (conv_run(a, -1, st)) return -1;
+        break;
+      }
+      case OP_MAXPOOL: {
+        const TensorDesc& xd = tensors[op.x];
+        const TensorDesc& yd = tensors[op.y];
+        PoolArgs a;
+        memset(&a, 0, sizeof(a));
+        a.x = ptr(op.x);
+        a.y = ptr(op.y);
+        a.y2 = ptr(op.y2);
+        a.scale2 = op.d_scale2;
+        a.shift2 = op.d_shift2;
+        a.N = n;
+        a.H = xd.H;
+        a.W = xd.W;
+        a.C = xd.C;
+        a.Ho = yd.H;
+        a.Wo = yd.W;
+        a.k = op.KH;
+        a.stride = op.stride;
+        a.pad_t = op.pad_t;
+        a.pad_l = op.pad_l;
+        a.zero_pad = op.zero_pad;
+        a.act2 = op.act2;
+        if (maxpool_run(a, st)) return -1;
+        break;
+      }
+      case OP_DWFULL: {
+        const TensorDesc& xd = tensors[op.x];
+        if (dwfull_run(ptr(op.x), op.d_w, op.d_scale, op.d_shift, ptr(op.y), n, xd.H * xd.W, xd.C, st)) return -1;
+        break;
+      }
+      case OP_L2NORM:
+        if (l2norm_run(ptr(op.x), ptr(op.y), n, op.Cout, 1e-12f, st)) return -1;
+        break;
+    }
+  }
+  return 0;
+}
+
+}  // namespace dif

@@ -1,0 +1,101 @@
+// Embedding network: a static list of layer ops over pooled NHWC activation buffers,
+// executed as a fixed sequence of kernel launches on the caller's stream.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "ops.hpp"
+
+namespace dif {
+
+struct Param {
+  std::string name;
+  std::vector<int64_t> shape;
+  std::vector<float> data;
+  bool set = false;
+  int64_t count() const {
+    int64_t n = 1;
+    for (auto s : shape) n *= s;
+    return n;
+  }
+};
+
+struct BNRef {
+  int gamma = -1, beta = -1, mean = -1, var = -1;
+  float eps = 0.f;
+  bool valid() const { return gamma >= 0; }
+};
+
+struct TensorDesc {
+  int H = 0, W = 0, C = 0;
+  int buf = -1;
+  int first_def = -1, last_use = -1;
+  int64_t elems() const { return (int64_t)H * W * C; }
+};
+
+enum OpKind { OP_INPUT, OP_CONV, OP_MAXPOOL, OP_DWFULL, OP_L2NORM };
+
+struct Op {
+  OpKind kind = OP_CONV;
+  std::string name;
+  int x = -1, y = -1, y2 = -1, res = -1;
+  // conv / pool geometry
+  int KH = 1, KW = 1, stride = 1, pad_t = 0, pad_l = 0;
+  int Cin = 0, Cin_true = 0, Cout = 0;
+  int res_stride = 1;
+  int zero_pad = 0;
+  bool chw_flatten = false;   // dense after an NCHW-order flatten: permute kernel rows at pack time
+  // parameters
+  int w = -1, bias = -1, alpha = -1, alpha2 = -1;
+  BNRef bn, bn2;
+  int act = ACT_NONE, act2 = ACT_NONE;
+  // device side (filled by finalize)
+  float* d_w = nullptr;
+  float* d_scale = nullptr;
+  float* d_shift = nullptr;
+  float* d_alpha = nullptr;
+  float* d_scale2 = nullptr;
+  float* d_shift2 = nullptr;
+  float* d_alpha2 = nullptr;
+  int Kpad = 0;
+  double macs = 0;   // per image
+};
+
+struct Net {
+  std::string arch, head;
+  int emd = 0, in_h = 0, in_w = 0;
+  std::vector<Param> params;
+  std::map<std::string, int> pindex;
+  std::vector<TensorDesc> tensors;
+  std::vector<Op> ops;
+  int input_tensor = -1, output_tensor = -1;
+  float in_scale = 1.f;
+  float in_bias[3] = {0.f, 0.f, 0.f};
+  int bgr = 0;
+  // finalize state
+  bool finalized = false;
+  int max_batch = 0;
+  std::vector<void*> allocs;
+  std::vector<float*> bufs;
+  std::vector<int64_t> buf_elems;   // per image
+
+  ~Net();
+  int build();                       // dispatch on arch/head
+  int finalize(int max_batch);
+  int embed(const void* x, int n, int layout, int dtype, float* out, hipStream_t st);
+  double flops_per_image() const;
+  void release_device();
+
+  // builder helpers
+  int P(const std::string& name, std::vector<int64_t> shape);
+  BNRef BN(const std::string& prefix, int C, float eps);
+  int T(int H, int W, int C);
+  int conv(const std::string& name, int x, int KH, int KW, int stride, int pad, int Cout, bool bias,
+           const BNRef& bn, int act, int alpha, int res, int res_stride, bool want_y, const BNRef& bn2, int act2,
+           int* y2_out, const std::string& wsuffix = "/kernel", bool same_pad_even = false);
+  int build_resnet50v2();
+  int build_iresnet(const int* layers);
+};
+
+}  // namespace dif

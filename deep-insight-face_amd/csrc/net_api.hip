@@ -1,22 +1,158 @@
-// placeholder until the conv engine lands
+// C ABI entry points of the embedding network and the ArcMargin head (include/dif.h).
+#include <new>
+#include <string.h>
+
 #include "../../include/dif.h"
+#include "arcmargin.hpp"
 #include "dif_internal.hpp"
+#include "net.hpp"
+
 using namespace dif;
+
+struct dif_net {
+  Net net;
+};
+struct dif_arcmargin {
+  ArcMargin a;
+};
+
 extern "C" {
-int dif_net_create(dif_net**, const char*, const char*, int, int, int) { return set_error("not built yet"); }
-int dif_net_destroy(dif_net*) { return 0; }
-int dif_net_param_count(const dif_net*) { return 0; }
-int dif_net_param_info(const dif_net*, int, const char**, int*, int64_t*) { return set_error("not built yet"); }
-int dif_net_set_param(dif_net*, const char*, const float*, int64_t) { return set_error("not built yet"); }
-int dif_net_get_param(const dif_net*, const char*, float*, int64_t) { return set_error("not built yet"); }
-int dif_net_set_input_transform(dif_net*, float, const float*, int) { return set_error("not built yet"); }
-int dif_net_finalize(dif_net*, int) { return set_error("not built yet"); }
-int dif_net_output_dim(const dif_net*, int64_t*) { return set_error("not built yet"); }
-int dif_net_embed(dif_net*, const void*, int, int, int, float*, void*) { return set_error("not built yet"); }
-double dif_net_flops_per_image(const dif_net*) { return 0; }
-int dif_net_launch_count(const dif_net*) { return 0; }
-int dif_arcmargin_create(dif_arcmargin**, int, int64_t, float, float) { return set_error("not built yet"); }
-int dif_arcmargin_destroy(dif_arcmargin*) { return 0; }
-int dif_arcmargin_set_weight(dif_arcmargin*, const float*, void*) { return set_error("not built yet"); }
-int dif_arcmargin_logits(dif_arcmargin*, const float*, const int64_t*, int, float*, void*) { return set_error("not built yet"); }
+
+int dif_net_create(dif_net** out, const char* arch, const char* head, int emd_size, int in_h, int in_w) {
+  if (!out || !arch) return set_error("dif_net_create: null argument");
+  dif_net* h = new (std::nothrow) dif_net();
+  if (!h) return set_error("dif_net_create: out of host memory");
+  h->net.arch = arch;
+  h->net.head = head ? head : "v2";
+  h->net.emd = emd_size;
+  h->net.in_h = in_h;
+  h->net.in_w = in_w;
+  if (h->net.build()) {
+    delete h;
+    return -1;
+  }
+  *out = h;
+  return 0;
 }
+
+int dif_net_destroy(dif_net* h) {
+  delete h;
+  return 0;
+}
+
+int dif_net_param_count(const dif_net* h) { return h ? (int)h->net.params.size() : 0; }
+
+int dif_net_param_info(const dif_net* h, int i, const char** name, int* ndim, int64_t shape[4]) {
+  if (!h || i < 0 || i >= (int)h->net.params.size()) return set_error("dif_net_param_info: index out of range");
+  const Param& p = h->net.params[i];
+  if (name) *name = p.name.c_str();
+  if (ndim) *ndim = (int)p.shape.size();
+  if (shape)
+    for (size_t k = 0; k < 4; ++k) shape[k] = k < p.shape.size() ? p.shape[k] : 1;
+  return 0;
+}
+
+int dif_net_set_param(dif_net* h, const char* name, const float* data_host, int64_t count) {
+  if (!h || !name || !data_host) return set_error("dif_net_set_param: null argument");
+  auto it = h->net.pindex.find(name);
+  if (it == h->net.pindex.end()) return set_error("dif_net_set_param: no parameter named '%s'", name);
+  Param& p = h->net.params[it->second];
+  if (count != p.count())
+    return set_error("dif_net_set_param: '%s' has %lld elements, got %lld", name, (long long)p.count(),
+                     (long long)count);
+  p.data.assign(data_host, data_host + count);
+  p.set = true;
+  h->net.finalized = false;   // weights changed: finalize again before the next forward
+  return 0;
+}
+
+int dif_net_get_param(const dif_net* h, const char* name, float* data_host, int64_t count) {
+  if (!h || !name || !data_host) return set_error("dif_net_get_param: null argument");
+  auto it = h->net.pindex.find(name);
+  if (it == h->net.pindex.end()) return set_error("dif_net_get_param: no parameter named '%s'", name);
+  const Param& p = h->net.params[it->second];
+  if (!p.set) return set_error("dif_net_get_param: '%s' was never set", name);
+  if (count != p.count()) return set_error("dif_net_get_param: '%s' size mismatch", name);
+  memcpy(data_host, p.data.data(), (size_t)count * sizeof(float));
+  return 0;
+}
+
+int dif_net_set_input_transform(dif_net* h, float scale, const float bias[3], int bgr) {
+  if (!h) return set_error("dif_net_set_input_transform: null handle");
+  h->net.in_scale = scale;
+  for (int k = 0; k < 3; ++k) h->net.in_bias[k] = bias ? bias[k] : 0.f;
+  h->net.bgr = bgr ? 1 : 0;
+  return 0;
+}
+
+int dif_net_finalize(dif_net* h, int max_batch) {
+  if (!h) return set_error("dif_net_finalize: null handle");
+  return h->net.finalize(max_batch);
+}
+
+int dif_net_output_dim(const dif_net* h, int64_t shape[3]) {
+  if (!h || !shape) return set_error("dif_net_output_dim: null argument");
+  const TensorDesc& t = h->net.tensors[h->net.output_tensor];
+  shape[0] = t.C;
+  shape[1] = t.H;
+  shape[2] = t.W;
+  return 0;
+}
+
+int dif_net_embed(dif_net* h, const void* x_dev, int n, int layout, int dtype, float* out_dev, void* stream) {
+  if (!h) return set_error("dif_net_embed: null handle");
+  return h->net.embed(x_dev, n, layout, dtype, out_dev, (hipStream_t)stream);
+}
+
+double dif_net_flops_per_image(const dif_net* h) { return h ? h->net.flops_per_image() : 0.0; }
+
+int dif_net_launch_count(const dif_net* h) { return h ? (int)h->net.ops.size() : 0; }
+
+// ------------------------------------------------------------------ ArcMargin
+int dif_arcmargin_create(dif_arcmargin** out, int d, int64_t n_classes, float s, float m) {
+  if (!out) return set_error("dif_arcmargin_create: null out");
+  if (d <= 0 || d % 32 != 0) return set_error("dif_arcmargin_create: d must be a positive multiple of 32");
+  if (n_classes <= 0) return set_error("dif_arcmargin_create: n_classes must be positive");
+  dif_arcmargin* h = new (std::nothrow) dif_arcmargin();
+  if (!h) return set_error("dif_arcmargin_create: out of host memory");
+  h->a.d = d;
+  h->a.C = n_classes;
+  h->a.s = s;
+  h->a.m = m;
+  if (hipMalloc(&h->a.w, (size_t)n_classes * d * sizeof(float)) != hipSuccess ||
+      hipMalloc(&h->a.winv, (size_t)n_classes * sizeof(float)) != hipSuccess) {
+    dif_arcmargin_destroy(h);
+    return set_error("dif_arcmargin_create: device allocation failed");
+  }
+  *out = h;
+  return 0;
+}
+
+int dif_arcmargin_destroy(dif_arcmargin* h) {
+  if (!h) return 0;
+  if (h->a.w) (void)hipFree(h->a.w);
+  if (h->a.winv) (void)hipFree(h->a.winv);
+  if (h->a.einv) (void)hipFree(h->a.einv);
+  delete h;
+  return 0;
+}
+
+int dif_arcmargin_set_weight(dif_arcmargin* h, const float* w_dev, void* stream) {
+  if (!h || !w_dev) return set_error("dif_arcmargin_set_weight: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  DIF_HIP(hipMemcpyAsync(h->a.w, w_dev, (size_t)h->a.C * h->a.d * sizeof(float), hipMemcpyDeviceToDevice, st));
+  h->a.has_weight = true;
+  return arcmargin_prepare(&h->a, st);
+}
+
+int dif_arcmargin_logits(dif_arcmargin* h, const float* emb_dev, const int64_t* labels_dev, int n,
+                         float* logits_dev, void* stream) {
+  if (!h) return set_error("dif_arcmargin_logits: null handle");
+  if (!h->a.has_weight) return set_error("dif_arcmargin_logits: class centres were never set");
+  if (n < 0) return set_error("dif_arcmargin_logits: negative batch");
+  if (n == 0) return 0;
+  if (!emb_dev || !logits_dev) return set_error("dif_arcmargin_logits: null pointer");
+  return arcmargin_run(&h->a, emb_dev, labels_dev, n, logits_dev, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,189 @@
+"""Embedding-model builder with the reference's constructor, backed by libdif.so.
+
+Reference: deep_insight_face/networks/triplet.py:60-146 (``bottleneck_network``): pick a
+backbone by name, then ``__call__(default_model_ver)`` returns a model object whose
+``predict_on_batch(x[N,H,W,3]) -> [N,emd]`` the rest of the code base calls
+(predictions.py:96,156; evaluation/evals.py:56).  Here the returned object is a
+``DifEmbedder``: same duck type, forward pass = hand-written HIP kernels on the MI355X.
+"""
+import ctypes
+import typing
+
+import numpy as np
+import torch
+
+from .. import _native as N
+from . import weights as W
+
+
+class DifEmbedder:
+    """Keras-model stand-in: ``predict_on_batch``, ``__call__``, ``predict``,
+    ``load_weights``, ``save_weights`` (networks/inceptionv3.py:73-91, api.py:87)."""
+
+    def __init__(self, arch='resnet', head='v2', emd_size=128, input_shape=(112, 112, 3), max_batch=256, name=None):
+        if len(input_shape) != 3 or input_shape[2] != 3:
+            raise ValueError('input_shape must be (H, W, 3), got %r' % (input_shape,))
+        self.arch, self.head, self.emd_size = arch, head, int(emd_size)
+        self.input_shape = tuple(int(s) for s in input_shape)
+        self.max_batch = int(max_batch)
+        self.name = name or arch
+        self._h = ctypes.c_void_p()
+        N.check(N.lib.dif_net_create(ctypes.byref(self._h), arch.encode(), head.encode(), self.emd_size,
+                                     self.input_shape[0], self.input_shape[1]), ValueError)
+        self._ready = False
+        shp = (ctypes.c_int64 * 3)()
+        N.check(N.lib.dif_net_output_dim(self._h, shp))
+        c, h, w = int(shp[0]), int(shp[1]), int(shp[2])
+        self.output_shape = (c,) if (h == 1 and w == 1) else (h, w, c)
+
+    # ---- parameters -----------------------------------------------------------------
+    def param_spec(self):
+        out = []
+        name, ndim, shape = ctypes.c_char_p(), ctypes.c_int(), (ctypes.c_int64 * 4)()
+        for i in range(N.lib.dif_net_param_count(self._h)):
+            N.check(N.lib.dif_net_param_info(self._h, i, ctypes.byref(name), ctypes.byref(ndim), shape))
+            out.append((name.value.decode(), tuple(int(shape[k]) for k in range(ndim.value))))
+        return out
+
+    def count_params(self):
+        return int(sum(int(np.prod(s)) for _, s in self.param_spec()))
+
+    def set_weights(self, params: typing.Mapping[str, np.ndarray]):
+        spec = dict(self.param_spec())
+        missing = sorted(set(spec) - set(params))
+        if missing:
+            raise ValueError('missing weights: %s%s' % (missing[:5], ' ...' if len(missing) > 5 else ''))
+        for name, shape in spec.items():
+            a = np.ascontiguousarray(params[name], dtype=np.float32)
+            if tuple(a.shape) != shape:
+                raise ValueError('weight %s has shape %s, expected %s' % (name, a.shape, shape))
+            N.check(N.lib.dif_net_set_param(self._h, name.encode(), a.ctypes.data_as(ctypes.c_void_p), a.size),
+                    ValueError)
+        self._ready = False
+
+    def get_weights(self):
+        out = {}
+        for name, shape in self.param_spec():
+            a = np.empty(shape, dtype=np.float32)
+            N.check(N.lib.dif_net_get_param(self._h, name.encode(), a.ctypes.data_as(ctypes.c_void_p), a.size),
+                    ValueError)
+            out[name] = a
+        return out
+
+    def init_synthetic(self, seed=2024):
+        """Seeded random weights (no pretrained weights are obtainable offline)."""
+        self.set_weights(W.synth_params(self.param_spec(), seed))
+        return self
+
+    def load_weights(self, path):
+        if str(path).endswith(('.h5', '.hdf5')):
+            raise ValueError('Keras HDF5 weights need h5py, which is not available here; convert to .npz '
+                             '(one entry per Keras weight name) and load that')
+        self.set_weights(W.load_npz(path))
+
+    def save_weights(self, path):
+        W.save_npz(path, self.get_weights())
+
+    def set_input_transform(self, scale=1.0, bias=(0.0, 0.0, 0.0), bgr=False):
+        """y[c] = x[2-c if bgr else c] * scale + bias[c], fused into the first kernel."""
+        b = (ctypes.c_float * 3)(*[float(v) for v in bias])
+        N.check(N.lib.dif_net_set_input_transform(self._h, float(scale), b, int(bool(bgr))))
+
+    def _finalize(self):
+        if not self._ready:
+            N.require_device()
+            N.check(N.lib.dif_net_finalize(self._h, self.max_batch))
+            self._ready = True
+
+    @property
+    def flops_per_image(self):
+        return float(N.lib.dif_net_flops_per_image(self._h))
+
+    # ---- forward ----------------------------------------------------------------------
+    def embed(self, x, layout=None):
+        """x: torch tensor or ndarray, [N,H,W,3] (NHWC, the reference's layout) or
+        [N,3,H,W] (NCHW), float or uint8.  Returns a float32 CUDA tensor [N, *output_shape]."""
+        dev = N.require_device()
+        self._finalize()
+        t = torch.from_numpy(np.ascontiguousarray(x)) if not torch.is_tensor(x) else x
+        if t.dim() != 4:
+            raise ValueError('expected a 4-D batch, got shape %s' % (tuple(t.shape),))
+        H, Wd, _ = self.input_shape
+        if layout is None:
+            if tuple(t.shape[1:]) == (H, Wd, 3):
+                layout = N.LAYOUT_NHWC
+            elif tuple(t.shape[1:]) == (3, H, Wd):
+                layout = N.LAYOUT_NCHW
+            else:
+                raise ValueError('input %s matches neither [N,%d,%d,3] nor [N,3,%d,%d]'
+                                 % (tuple(t.shape), H, Wd, H, Wd))
+        if t.dtype == torch.uint8:
+            dtype = N.DTYPE_U8
+        else:
+            dtype = N.DTYPE_F32
+            t = t.to(torch.float32)
+        t = t.to(dev).contiguous()
+        n = t.shape[0]
+        out = torch.empty((n,) + self.output_shape, dtype=torch.float32, device=dev)
+        per = int(np.prod(self.output_shape))
+        flat = out.view(n, per)
+        for s in range(0, n, self.max_batch):
+            e = min(n, s + self.max_batch)
+            N.check(N.lib.dif_net_embed(self._h, N.ptr(t[s:e]), e - s, layout, dtype, N.ptr(flat[s:e]),
+                                        N.stream_ptr()))
+        return out
+
+    def predict_on_batch(self, x):
+        """NumPy in -> NumPy float32 out (Keras semantics); torch in -> CUDA tensor out."""
+        out = self.embed(x)
+        return out if torch.is_tensor(x) else out.cpu().numpy()
+
+    __call__ = predict_on_batch
+
+    def predict(self, x, batch_size=None, **_):
+        return self.predict_on_batch(x)
+
+    def close(self):
+        if self._h:
+            N.lib.dif_net_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class bottleneck_network:
+    """Same constructor and call as the reference (networks/triplet.py:73-85).  ``net`` is
+    'resnet' (ResNet50V2, the hot path) or -- extensions named by north_star --
+    'iresnet50' / 'iresnet100'.  'mobilenet' / 'vgg16' are accepted names in the reference
+    but are not part of the accelerated path."""
+
+    def __init__(self, net: str = "resnet", emd_size: int = 128, input_shape: typing.Tuple = (96, 96, 3), **kwargs):
+        assert net in ('mobilenet', 'resnet', 'vgg16', 'iresnet50', 'iresnet100'), "Invalid bottleneck network"
+        if net in ('mobilenet', 'vgg16'):
+            raise NotImplementedError("bottleneck '%s' is outside the MI355X hot path (resnet, iresnet50, iresnet100)"
+                                      % net)
+        self.net = net
+        self.emd_size = emd_size
+        self.input_shape = input_shape
+        self.kwargs = kwargs
+
+    def __call__(self, default_model_ver='v1', dropout=.2) -> DifEmbedder:
+        # dropout is identity at inference (triplet.py:133-134)
+        return getattr(self, 'build_models_' + default_model_ver)(dropout=dropout)
+
+    def _build(self, head):
+        return DifEmbedder(self.net, head, self.emd_size, self.input_shape,
+                           max_batch=self.kwargs.get('max_batch', 256))
+
+    def build_models_v1(self, dropout=0.3):
+        return self._build('v1')
+
+    def build_models_v2(self, dropout=0.3):
+        return self._build('v2')
+
+    def build_models_v3(self, dropout=0.3):
+        return self._build('v3')

@@ -1,0 +1,52 @@
+"""Weight containers for the embedding networks.
+
+* ``synth_params`` -- seeded synthetic weights: He-normal
+  kernels, BN gamma~U(0.5,1.5), beta~N(0,0.1), moving_mean~N(0,0.1),
+  moving_variance~U(0.5,1.5), PReLU alpha=0.25, biases~N(0,0.1).  No pretrained face
+  weights exist offline (the reference fetches ImageNet weights from the network,
+  networks/triplet.py:89-93), so benchmarks and parity tests use these.
+* ``save_npz`` / ``load_npz`` -- the on-disk format behind ``save_weights`` /
+  ``load_weights``: one ``.npz`` entry per parameter, keyed by the Keras-style name.
+"""
+import zlib
+
+import numpy as np
+
+
+def synth_params(spec, seed=2024):
+    """spec: iterable of (name, shape).  Each parameter gets its own stream seeded from
+    (seed, crc32(name)), so the values do not depend on the order of the table."""
+    out = {}
+    for name, shape in spec:
+        shape = tuple(int(s) for s in shape)
+        rng = np.random.default_rng([seed, zlib.crc32(name.encode())])
+        leaf = name.rsplit('/', 1)[-1]
+        if leaf in ('kernel', 'depthwise_kernel'):
+            if len(shape) == 4 and leaf == 'depthwise_kernel':
+                fan_in = shape[0] * shape[1]
+            elif len(shape) == 4:
+                fan_in = shape[0] * shape[1] * shape[2]
+            else:
+                fan_in = shape[0]
+            v = rng.standard_normal(shape) * np.sqrt(2.0 / fan_in)
+        elif leaf == 'gamma':
+            v = rng.uniform(0.5, 1.5, shape)
+        elif leaf in ('beta', 'moving_mean', 'bias'):
+            v = rng.standard_normal(shape) * 0.1
+        elif leaf == 'moving_variance':
+            v = rng.uniform(0.5, 1.5, shape)
+        elif leaf == 'alpha':
+            v = np.full(shape, 0.25)
+        else:
+            raise ValueError('unknown parameter kind: %s' % name)
+        out[name] = np.ascontiguousarray(v, dtype=np.float32)
+    return out
+
+
+def save_npz(path, params):
+    np.savez(path, **{k.replace('/', '::'): v for k, v in params.items()})
+
+
+def load_npz(path):
+    with np.load(path) as z:
+        return {k.replace('::', '/'): np.ascontiguousarray(z[k], dtype=np.float32) for k in z.files}

@@ -1,0 +1,163 @@
+"""Parity of the HIP embedding forward (through the C ABI) against the CPU oracle on
+the same seeded crops and weights.  Tolerance (north_star): cosine distances within 1e-5
+in float32, arg-min identities bit-identical."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import distance as od
+from oracle import nets
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def crops_u8(n, hw=112, seed=1234):
+    return np.random.default_rng(seed).integers(0, 256, (n, hw, hw, 3), dtype=np.uint8)
+
+
+def scaled(u8):
+    return u8.astype(np.float32) / np.float32(255.0)
+
+
+def cosine_gap(a, b):
+    a = a.reshape(a.shape[0], -1).astype(np.float64)
+    b = b.reshape(b.shape[0], -1).astype(np.float64)
+    return 1.0 - (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+
+
+def build(arch, head, emd, max_batch=8):
+    from deep_insight_face.networks.triplet import bottleneck_network
+    model = bottleneck_network(arch, emd, (112, 112, 3), max_batch=max_batch)(head)
+    model.init_synthetic(2024)
+    return model, model.get_weights()
+
+
+@pytest.mark.parametrize('arch,head,emd,n', [('resnet', 'v2', 512, 8), ('resnet', 'v1', 128, 5),
+                                             ('resnet', 'v3', 512, 3), ('iresnet50', 'v2', 512, 3),
+                                             ('iresnet100', 'v2', 512, 2)])
+def test_embed_vs_oracle(cuda, arch, head, emd, n):
+    model, p = build(arch, head, emd)
+    x = scaled(crops_u8(n))
+    got = model.predict_on_batch(x)
+    want = nets.embed(x, p, arch, emd, head)
+    assert isinstance(got, np.ndarray) and got.dtype == np.float32 and got.shape == want.shape
+    assert np.all(np.isfinite(got))
+    gap = cosine_gap(got, want)
+    assert gap.max() < TOL, gap
+    scale = np.abs(want).max()
+    np.testing.assert_allclose(got, want, atol=2e-4 * scale, rtol=2e-3)
+    if head != 'v3':
+        # every pairwise cosine distance between embeddings agrees within 1e-5
+        for i in range(n):
+            a = od.distance(np.repeat(got[i][None], n, 0), got, 1)
+            b = od.distance(np.repeat(want[i][None], n, 0), want, 1)
+            mask = np.arange(n) != i
+            np.testing.assert_allclose(a[mask], b[mask], atol=TOL)
+    model.close()
+
+
+def test_config1_embed_then_match(cuda):
+    """BASELINE config 1 (ResNet-50 512-d, batch 8, 1k gallery): identities found through
+    the HIP embed + HIP match equal those of the oracle embed + reference-formula match."""
+    from deep_insight_face import oneshot
+    model, p = build('resnet', 'v2', 512, max_batch=64)
+    enrolled = scaled(crops_u8(40, seed=5))
+    probes_u8 = crops_u8(40, seed=5)[[3, 17, 0, 39, 21, 8, 30, 11]]
+    noise = np.random.default_rng(9).integers(-6, 7, probes_u8.shape)
+    probes = scaled(np.clip(probes_u8.astype(np.int64) + noise, 0, 255).astype(np.uint8))
+    filler = np.random.default_rng(10).standard_normal((960, 512)).astype(np.float32)
+    filler /= np.linalg.norm(filler, axis=1, keepdims=True)
+
+    g_emb = model.predict_on_batch(enrolled)
+    q_emb = model.predict_on_batch(probes)
+    o_g = nets.embed(enrolled, p, 'resnet', 512, 'v2')
+    o_q = nets.embed(probes, p, 'resnet', 512, 'v2')
+    gal = oneshot.Gallery(np.concatenate([g_emb, filler]))
+    for m in (0, 1):
+        idx, dist = gal.match(q_emb, m)
+        oi, odist, _ = od.match(o_q, np.concatenate([o_g, filler]), m)
+        assert np.array_equal(idx, oi)
+        assert np.array_equal(idx, [3, 17, 0, 39, 21, 8, 30, 11])
+        if m == 0:
+            np.testing.assert_allclose(dist, odist, atol=TOL)
+        else:
+            np.testing.assert_allclose(np.cos(dist.astype(np.float64) * np.pi),
+                                       np.cos(odist.astype(np.float64) * np.pi), atol=TOL)
+    gal.close()
+    model.close()
+
+
+def test_input_forms_agree(cuda):
+    """NHWC float (the reference's form), NCHW float, uint8 + fused 1/255 scaling, torch
+    CUDA tensors and batches larger than max_batch all give the same embeddings."""
+    model, _ = build('resnet', 'v2', 512, max_batch=4)
+    u8 = crops_u8(6)
+    x = scaled(u8)
+    base = model.predict_on_batch(x)
+    nchw = model.predict_on_batch(np.ascontiguousarray(x.transpose(0, 3, 1, 2)))
+    assert np.array_equal(base, nchw)
+    t = model.predict_on_batch(torch.from_numpy(x).cuda())
+    assert torch.is_tensor(t) and t.is_cuda and np.array_equal(t.cpu().numpy(), base)
+    model.set_input_transform(scale=1 / 255.)
+    fused = model.predict_on_batch(u8)
+    fused_nchw = model.predict_on_batch(np.ascontiguousarray(u8.transpose(0, 3, 1, 2)))
+    model.set_input_transform()
+    assert cosine_gap(fused, base).max() < 1e-6
+    assert np.array_equal(fused, fused_nchw)
+    # batch invariance and determinism: a row's embedding does not depend on its batch
+    one = model.predict_on_batch(x[2:3])
+    assert np.array_equal(one[0], base[2])
+    assert np.array_equal(model.predict_on_batch(x), base)
+    with pytest.raises(ValueError):
+        model.predict_on_batch(np.zeros((2, 96, 96, 3), dtype=np.float32))
+    model.close()
+
+
+def test_bgr_mean_transform(cuda):
+    """The siamese path's keras vgg16 preprocess_input (predictions.py:95): BGR swap and
+    mean subtraction, fused into the input kernel."""
+    model, p = build('resnet', 'v2', 512, max_batch=4)
+    x = scaled(crops_u8(2, seed=3))
+    mean = np.array([103.939, 116.779, 123.68], dtype=np.float32)
+    want = nets.embed(x[..., ::-1] - mean, p, 'resnet', 512, 'v2')
+    model.set_input_transform(scale=1.0, bias=tuple(-mean), bgr=True)
+    got = model.predict_on_batch(x)
+    assert cosine_gap(got, want).max() < TOL
+    model.close()
+
+
+def test_weights_roundtrip(cuda, tmp_path):
+    model, p = build('resnet', 'v1', 128, max_batch=2)
+    x = scaled(crops_u8(2))
+    a = model.predict_on_batch(x)
+    path = str(tmp_path / 'w.npz')
+    model.save_weights(path)
+    from deep_insight_face.networks.triplet import DifEmbedder
+    other = DifEmbedder('resnet', 'v1', 128, (112, 112, 3), max_batch=2)
+    with pytest.raises(Exception):
+        other.predict_on_batch(x)           # weights never set
+    other.load_weights(path)
+    assert np.array_equal(other.predict_on_batch(x), a)
+    with pytest.raises(ValueError):
+        other.set_weights({k: v for k, v in p.items() if 'post_bn' not in k})
+    model.close()
+    other.close()
+
+
+def test_arcmargin_vs_oracle(cuda):
+    from deep_insight_face.networks.arcmargin import ArcMarginHead
+    rng = np.random.default_rng(0)
+    for (B, C) in ((5, 100), (130, 1000), (64, 4097)):
+        e = rng.standard_normal((B, 512)).astype(np.float32)
+        w = rng.standard_normal((C, 512)).astype(np.float32)
+        lab = rng.integers(0, C, (B,))
+        head = ArcMarginHead(w)
+        got = head.logits(e)
+        want = nets.arcmargin_logits(e, w)
+        np.testing.assert_allclose(got, want, atol=64 * TOL)
+        gotm = head.logits(e, lab)
+        wantm = nets.arcmargin_logits(e, w, lab)
+        np.testing.assert_allclose(gotm, wantm, atol=64 * 2e-5)
+        assert np.array_equal(np.argmax(got, 1), np.argmax(want, 1))
+        head.close()

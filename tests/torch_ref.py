@@ -1,0 +1,96 @@
+"""Independent torch-CPU (NCHW, torch.nn.functional) implementation of the embedding
+networks, used to cross-check the NumPy oracle (oracle/nets.py is "parity unpinned":
+no reference arithmetic exists for the backbones, so two independently written
+implementations must agree).  Not the reference, not the product."""
+import torch
+import torch.nn.functional as F
+
+
+def _t(p, name):
+    return torch.from_numpy(p[name])
+
+
+def _conv(x, p, name, stride=1, pad=0, bias=True):
+    w = _t(p, name + '/kernel').permute(3, 2, 0, 1).contiguous()      # HWIO -> OIHW
+    b = _t(p, name + '/bias') if bias and (name + '/bias') in p else None
+    if isinstance(pad, tuple):                                         # (left, right, top, bottom)
+        x = F.pad(x, pad)
+        pad = 0
+    return F.conv2d(x, w, b, stride=stride, padding=pad)
+
+
+def _bn(x, p, name, eps):
+    return F.batch_norm(x, _t(p, name + '/moving_mean'), _t(p, name + '/moving_variance'),
+                        _t(p, name + '/gamma'), _t(p, name + '/beta'), False, 0.0, eps)
+
+
+def resnet50v2(x, p):
+    eps = 1.001e-5
+    y = _conv(x, p, 'conv1_conv', 2, 3)
+    y = F.max_pool2d(F.pad(y, (1, 1, 1, 1)), 3, 2)
+    for si, (f, blocks, s1) in enumerate(((64, 3, 2), (128, 4, 2), (256, 6, 2), (512, 3, 1))):
+        for b in range(1, blocks + 1):
+            n = 'conv%d_block%d' % (si + 2, b)
+            stride = s1 if b == blocks else 1
+            pre = F.relu(_bn(y, p, n + '_preact_bn', eps))
+            if b == 1:
+                sc = _conv(pre, p, n + '_0_conv', stride)
+            else:
+                sc = F.max_pool2d(y, 1, stride) if stride > 1 else y
+            z = F.relu(_bn(_conv(pre, p, n + '_1_conv', bias=False), p, n + '_1_bn', eps))
+            z = F.relu(_bn(_conv(z, p, n + '_2_conv', stride, 1, bias=False), p, n + '_2_bn', eps))
+            y = sc + _conv(z, p, n + '_3_conv')
+    return F.relu(_bn(y, p, 'post_bn', eps))
+
+
+def head_gdc(f, p):
+    y = _bn(_conv(f, p, 'head_conv', bias=False), p, 'head_bn1', 1e-3)
+    y = F.prelu(y, _t(p, 'head_prelu/alpha'))
+    dw = _t(p, 'head_dw/depthwise_kernel').permute(2, 3, 0, 1).contiguous()     # [C,1,H,W]
+    y = F.conv2d(y, dw, groups=y.shape[1])
+    y = _bn(y, p, 'head_bn2', 1e-3)
+    y = _conv(y, p, 'head_pw', bias=False).flatten(1)
+    y = y @ _t(p, 'head_dense/kernel')
+    return y / y.pow(2).sum(1, keepdim=True).clamp_min(1e-12).sqrt()
+
+
+def head_v1(f, p):
+    y = F.relu(_conv(f, p, 'v1_conv1', pad=(0, 1, 0, 1)))
+    y = F.max_pool2d(y, 2)
+    y = F.relu(_conv(y, p, 'v1_conv2', pad=(0, 1, 0, 1)))
+    y = F.max_pool2d(y, 2)
+    y = y.permute(0, 2, 3, 1).flatten(1)                                # Keras flattens NHWC
+    return y @ _t(p, 'embeddings/kernel') + _t(p, 'embeddings/bias')
+
+
+def iresnet(x, p, layers):
+    eps = 1e-5
+    y = F.prelu(_bn(_conv(x, p, 'conv1', 1, 1, bias=False), p, 'bn1', eps), _t(p, 'prelu/alpha'))
+    for li, nblk in enumerate(layers):
+        for b in range(nblk):
+            n = 'layer%d_%d' % (li + 1, b)
+            stride = 2 if b == 0 else 1
+            z = _conv(_bn(y, p, n + '_bn1', eps), p, n + '_conv1', 1, 1, bias=False)
+            z = F.prelu(_bn(z, p, n + '_bn2', eps), _t(p, n + '_prelu/alpha'))
+            z = _bn(_conv(z, p, n + '_conv2', stride, 1, bias=False), p, n + '_bn3', eps)
+            sc = _bn(_conv(y, p, n + '_down_conv', stride, bias=False), p, n + '_down_bn', eps) if b == 0 else y
+            y = z + sc
+    y = _bn(y, p, 'bn2', eps).flatten(1)                                 # NCHW flatten: c*HW + h*W + w
+    y = y @ _t(p, 'fc/kernel') + _t(p, 'fc/bias')
+    y = F.batch_norm(y, _t(p, 'features/moving_mean'), _t(p, 'features/moving_variance'),
+                     _t(p, 'features/gamma'), _t(p, 'features/beta'), False, 0.0, eps)
+    return y / y.pow(2).sum(1, keepdim=True).clamp_min(1e-12).sqrt()
+
+
+def embed(x_nhwc, p, arch, head='v2'):
+    x = torch.from_numpy(x_nhwc).permute(0, 3, 1, 2).contiguous()
+    with torch.no_grad():
+        if arch == 'resnet':
+            f = resnet50v2(x, p)
+            if head == 'v2':
+                return head_gdc(f, p).numpy()
+            if head == 'v1':
+                return head_v1(f, p).numpy()
+            return f.permute(0, 2, 3, 1).contiguous().numpy()
+        layers = {'iresnet50': (3, 4, 14, 3), 'iresnet100': (3, 13, 30, 3)}[arch]
+        return iresnet(x, p, layers).numpy()
