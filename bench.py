@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Benchmark of the embedding + match hot path (BASELINE.json metric: faces/sec).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload r50|r100]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic crops already resident
+in HBM: uint8 NHWC crops -> embedding forward (HIP, f32 MFMA) -> [N>1: RCCL all-gather of
+the per-rank embeddings] -> top-1 cosine match against the (row-sharded) gallery ->
+[N>1: all-gather of the partial results + lowest-index merge].
+
+Default workload = BASELINE.json configs[1]: ResNet-50(V2)+GDC 512-d, batch 256 per GPU,
+100k-row gallery.  Weak scaling: the per-GPU batch is fixed, the gallery is fixed in total
+and row-sharded, so both the embed and the match work per GPU stay constant as N grows.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (the
+convolution kernel family against the f32 MFMA peak) and, at N=1, `cpu_baseline` (the CPU
+oracle = a port of the reference's algorithm, timed on this host's cores on a bounded
+sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, 'deep-insight-face_amd'))
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+WORKLOADS = {
+    # name: (arch, head, per-GPU batch, gallery rows in total, description)
+    'r50': ('resnet', 'v2', 256, 100_000,
+            'configs[1]: ResNet-50V2+GDC 512-d embed, batch=256/GPU, 100k gallery cosine match'),
+    'r100': ('iresnet100', 'v2', 256, 100_000,
+             'north_star target: IResNet-100 512-d embed, batch=256/GPU, 100k gallery cosine match'),
+}
+
+
+def synthetic_gallery(rows, d, seed, device):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    x = torch.randn((rows, d), generator=g, dtype=torch.float32)
+    return torch.nn.functional.normalize(x, dim=1).to(device)
+
+
+def cpu_baseline(arch, head, gallery_rows, sample=16):
+    """The oracle (NumPy port of the reference's algorithm) on a bounded sample of the same
+    workload: `sample` faces embedded with the same synthetic weights + matched against the
+    same-size gallery with the reference's distance formula."""
+    sys.path.insert(0, ROOT)
+    from oracle import distance as od
+    from oracle import nets
+    from deep_insight_face.networks.weights import synth_params
+    p = synth_params(nets.model_spec(arch, 512, 112, head))
+    rng = np.random.default_rng(1234)
+    x = rng.integers(0, 256, (sample, 112, 112, 3), dtype=np.uint8).astype(np.float32) / np.float32(255)
+    gal = rng.standard_normal((gallery_rows, 512)).astype(np.float32)
+    gal /= np.linalg.norm(gal, axis=1, keepdims=True)
+    nets.embed(x[:2], p, arch, 512, head)                     # warm the BLAS threads
+    t0 = time.perf_counter()
+    e = nets.embed(x, p, arch, 512, head)
+    t1 = time.perf_counter()
+    od.match(e, gal, 1)
+    t2 = time.perf_counter()
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count()
+    return {
+        'value': sample / (t2 - t0), 'unit': 'faces/s', 'cores': cores, 'kind': 'port',
+        'sample': '%d faces: oracle embed (NumPy/BLAS, %.2fs) + reference-formula match vs %d rows (%.2fs)'
+                  % (sample, t1 - t0, gallery_rows, t2 - t1),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--workload', default='r50', choices=sorted(WORKLOADS))
+    ap.add_argument('--batch', type=int, default=0, help='per-GPU batch override')
+    ap.add_argument('--gallery', type=int, default=0, help='total gallery rows override')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run (one process per GPU)' % args.gpus)
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit('bench.py needs a HIP device: the hot path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from deep_insight_face.networks.triplet import DifEmbedder
+    from deep_insight_face.parallel import ShardedGallery, shard_bounds
+
+    arch, head, batch, gallery_rows, desc = WORKLOADS[args.workload]
+    batch = args.batch or batch
+    gallery_rows = args.gallery or gallery_rows
+
+    model = DifEmbedder(arch, head, 512, (112, 112, 3), max_batch=batch).init_synthetic(2024)
+    model.set_input_transform(scale=1 / 255.)                 # predictions.py:154 `* rescale`, fused
+    lo, hi = shard_bounds(gallery_rows, world, rank)
+    gal_full = synthetic_gallery(gallery_rows, 512, 7, 'cpu')
+    shard = ShardedGallery(gal_full[lo:hi].to(dev), lo)
+    del gal_full
+    g = torch.Generator(device='cpu').manual_seed(1234 + rank)
+    crops = torch.randint(0, 256, (batch, 112, 112, 3), generator=g, dtype=torch.uint8).to(dev)
+
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+
+    def step(i=None):
+        if i is not None:
+            ev[i][0].record()
+        emb = model.embed(crops)
+        if i is not None:
+            ev[i][1].record()
+        idx, d = shard.match(emb, 1)
+        if i is not None:
+            ev[i][2].record()
+        return idx, d
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        idx, d = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    embed_ms = float(np.mean([ev[i][0].elapsed_time(ev[i][1]) for i in range(args.steps)]))
+    match_ms = float(np.mean([ev[i][1].elapsed_time(ev[i][2]) for i in range(args.steps)]))
+
+    if rank == 0:
+        flops_embed = model.flops_per_image * batch            # algorithmic: 2 * MACs of every conv/dense
+        achieved = flops_embed / (embed_ms * 1e-3) / 1e12
+        prof = model.profile(crops)
+        conv_ms = sum(ms for _, k, _, ms in prof if k.startswith('conv_igemm'))
+        conv_flops = sum(2 * macs * batch for _, k, macs, _ in prof if k.startswith('conv_igemm'))
+        out = {
+            'metric': 'faces/sec embedding+match (112x112, 512-d)',
+            'value': world * batch * args.steps / elapsed,
+            'unit': 'faces/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f32',
+            'data': 'synthetic (uint8 crops seed 1234, He-normal weights seed 2024, unit-norm gallery seed 7)',
+            'config': {'workload': desc, 'arch': arch, 'head': head, 'batch_per_gpu': batch,
+                       'global_batch': world * batch, 'gallery_rows': gallery_rows,
+                       'gallery_rows_per_gpu': hi - lo, 'emd': 512, 'metric': 'cosine',
+                       'parallelism': 'dp%d + gallery row-shard' % world},
+            'phases_ms': {'embed': embed_ms, 'match': match_ms},
+            'roofline': {
+                'bound': 'mfma', 'kernel': 'conv_igemm_kernel (f32 MFMA implicit-GEMM conv; one launch group = the '
+                                           '%d conv launches of one %s forward at batch %d)'
+                                           % (sum(1 for _, k, _, _ in prof if k.startswith('conv_igemm')), arch, batch),
+                'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                'algorithmic_flops_per_forward': flops_embed,
+                'forward_ms_hip_events': embed_ms,
+                'conv_only': {'ms': conv_ms, 'tflops': conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms else None},
+                'match': {'ms': match_ms,
+                          'tflops': 2.0 * world * batch * (hi - lo) * 512 / (match_ms * 1e-3) / 1e12},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(arch, head, gallery_rows)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

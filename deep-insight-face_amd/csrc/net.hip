@@ -492,7 +492,23 @@ int Net::finalize(int mb) {
 }
 
 // ----------------------------------------------------------------------------- forward
-int Net::embed(const void* xin, int n, int layout, int dtype, float* out, hipStream_t st) {
+const char* Net::kernel_name(const Op& op, int n) const {
+  switch (op.kind) {
+    case OP_INPUT: return "input_convert_kernel";
+    case OP_MAXPOOL: return "maxpool_kernel";
+    case OP_DWFULL: return "dwfull_kernel";
+    case OP_L2NORM: return "l2norm_kernel";
+    case OP_CONV: {
+      const TensorDesc& yd = tensors[op.y >= 0 ? op.y : op.y2];
+      static const char* names[4] = {"conv_igemm_kernel<2,2>", "conv_igemm_kernel<2,1>", "conv_igemm_kernel<1,2>",
+                                     "conv_igemm_kernel<1,1>"};
+      return names[conv_tile_choice((int64_t)n * yd.H * yd.W, op.Cout)];
+    }
+  }
+  return "?";
+}
+
+int Net::embed(const void* xin, int n, int layout, int dtype, float* out, hipStream_t st, float* op_ms) {
   if (!finalized) return set_error("dif_net_embed: call dif_net_finalize first");
   if (n < 0 || n > max_batch) return set_error("dif_net_embed: batch %d outside [0, max_batch=%d]", n, max_batch);
   if (n == 0) return 0;
@@ -504,6 +520,13 @@ int Net::embed(const void* xin, int n, int layout, int dtype, float* out, hipStr
     if (t == output_tensor) return out;
     return bufs[tensors[t].buf];
   };
+  std::vector<hipEvent_t> ev;
+  if (op_ms) {
+    ev.resize(ops.size() + 1);
+    for (auto& e : ev) DIF_HIP(hipEventCreate(&e));
+    DIF_HIP(hipEventRecord(ev[0], st));
+  }
+  int op_index = 0;
   for (const Op& op : ops) {
     switch (op.kind) {
       case OP_INPUT: {
@@ -601,6 +624,13 @@ int Net::embed(const void* xin, int n, int layout, int dtype, float* out, hipStr
         if (l2norm_run(ptr(op.x), ptr(op.y), n, op.Cout, 1e-12f, st)) return -1;
         break;
     }
+    ++op_index;
+    if (op_ms) DIF_HIP(hipEventRecord(ev[op_index], st));
+  }
+  if (op_ms) {
+    DIF_HIP(hipStreamSynchronize(st));
+    for (size_t i = 0; i < ops.size(); ++i) DIF_HIP(hipEventElapsedTime(&op_ms[i], ev[i], ev[i + 1]));
+    for (auto& e : ev) (void)hipEventDestroy(e);
   }
   return 0;
 }

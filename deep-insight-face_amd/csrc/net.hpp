@@ -83,7 +83,8 @@ struct Net {
   ~Net();
   int build();                       // dispatch on arch/head
   int finalize(int max_batch);
-  int embed(const void* x, int n, int layout, int dtype, float* out, hipStream_t st);
+  int embed(const void* x, int n, int layout, int dtype, float* out, hipStream_t st, float* op_ms = nullptr);
+  const char* kernel_name(const Op& op, int n) const;
   double flops_per_image() const;
   void release_device();
 

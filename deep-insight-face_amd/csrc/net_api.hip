@@ -108,6 +108,21 @@ double dif_net_flops_per_image(const dif_net* h) { return h ? h->net.flops_per_i
 
 int dif_net_launch_count(const dif_net* h) { return h ? (int)h->net.ops.size() : 0; }
 
+int dif_net_op_info(const dif_net* h, int i, const char** name, const char** kernel, double* macs_per_image) {
+  if (!h || i < 0 || i >= (int)h->net.ops.size()) return set_error("dif_net_op_info: index out of range");
+  const Op& op = h->net.ops[i];
+  if (name) *name = op.name.c_str();
+  if (kernel) *kernel = h->net.kernel_name(op, h->net.max_batch > 0 ? h->net.max_batch : 1);
+  if (macs_per_image) *macs_per_image = op.macs;
+  return 0;
+}
+
+int dif_net_embed_profile(dif_net* h, const void* x_dev, int n, int layout, int dtype, float* out_dev,
+                          void* stream, float* ms_host) {
+  if (!h || !ms_host) return set_error("dif_net_embed_profile: null argument");
+  return h->net.embed(x_dev, n, layout, dtype, out_dev, (hipStream_t)stream, ms_host);
+}
+
 // ------------------------------------------------------------------ ArcMargin
 int dif_arcmargin_create(dif_arcmargin** out, int d, int64_t n_classes, float s, float m) {
   if (!out) return set_error("dif_arcmargin_create: null out");

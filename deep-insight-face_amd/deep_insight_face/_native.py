@@ -49,6 +49,8 @@ SIGNATURES = {
     'dif_net_embed': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'dif_net_flops_per_image': (c_double, [c_void_p]),
     'dif_net_launch_count': (c_int, [c_void_p]),
+    'dif_net_op_info': (c_int, [c_void_p, c_int, P(c_char_p), P(c_char_p), P(c_double)]),
+    'dif_net_embed_profile': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, P(c_float)]),
     'dif_arcmargin_create': (c_int, [P(c_void_p), c_int, c_int64, c_float, c_float]),
     'dif_arcmargin_destroy': (c_int, [c_void_p]),
     'dif_arcmargin_set_weight': (c_int, [c_void_p, c_void_p, c_void_p]),

@@ -133,6 +133,28 @@ class DifEmbedder:
                                         N.stream_ptr()))
         return out
 
+    def profile(self, x):
+        """Per-launch milliseconds of one forward of a CUDA uint8/float batch (diagnostic):
+        list of (op name, kernel name, MACs per image, ms)."""
+        dev = N.require_device()
+        self._finalize()
+        t = x.to(dev).contiguous()
+        n = t.shape[0]
+        if n > self.max_batch:
+            raise ValueError('profile one batch of at most max_batch images')
+        layout = N.LAYOUT_NHWC if tuple(t.shape[1:]) == self.input_shape else N.LAYOUT_NCHW
+        dtype = N.DTYPE_U8 if t.dtype == torch.uint8 else N.DTYPE_F32
+        out = torch.empty((n,) + self.output_shape, dtype=torch.float32, device=dev)
+        k = N.lib.dif_net_launch_count(self._h)
+        ms = (ctypes.c_float * k)()
+        N.check(N.lib.dif_net_embed_profile(self._h, N.ptr(t), n, layout, dtype, N.ptr(out), N.stream_ptr(), ms))
+        rows = []
+        name, kern, macs = ctypes.c_char_p(), ctypes.c_char_p(), ctypes.c_double()
+        for i in range(k):
+            N.check(N.lib.dif_net_op_info(self._h, i, ctypes.byref(name), ctypes.byref(kern), ctypes.byref(macs)))
+            rows.append((name.value.decode(), kern.value.decode(), macs.value, float(ms[i])))
+        return rows
+
     def predict_on_batch(self, x):
         """NumPy in -> NumPy float32 out (Keras semantics); torch in -> CUDA tensor out."""
         out = self.embed(x)

@@ -104,8 +104,14 @@ int dif_net_output_dim(const dif_net* net, int64_t shape[3]); /* {emd,1,1} or {C
 int dif_net_embed(dif_net* net, const void* x_dev, int n, int layout, int dtype, float* out_dev, void* stream);
 /* algorithmic FLOPs of one forward per image (2 * MACs of every conv/dense), for rooflines */
 double dif_net_flops_per_image(const dif_net* net);
-/* debugging / profiling aid: number of kernel launches per forward */
+/* profiling aids: number of layer ops (= kernel launches) per forward, their names and
+ * algorithmic MACs per image, and a forward that brackets every launch with HIP events on
+ * `stream` and returns the per-op milliseconds (ms_host[dif_net_launch_count]).  The
+ * profiled forward synchronises the stream; it is a diagnostic, never the timed path. */
 int dif_net_launch_count(const dif_net* net);
+int dif_net_op_info(const dif_net* net, int i, const char** name, const char** kernel, double* macs_per_image);
+int dif_net_embed_profile(dif_net* net, const void* x_dev, int n, int layout, int dtype, float* out_dev,
+                          void* stream, float* ms_host);
 
 /* ------------------------------------------------------------------ ArcMargin logits
  * Not in the reference (north_star only; ArcFace, Deng et al. 2019):

@@ -1,0 +1,84 @@
+"""The N>1 data path (all-gather of per-rank embeddings -> gallery-sharded match ->
+all-gather of partials -> lowest-index merge) with world_size 2 and 3 on the gloo
+backend, CPU only.  The local compute is stood in by the oracle (the HIP kernels need
+a GPU; their sharded-merge parity is covered by tests/test_match_gpu.py)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import golden_inputs as gi
+from oracle import distance as od
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_match(gallery, probes, metric):
+    rows, base = gallery
+    idx, best, _ = od.match(probes.numpy(), rows, metric)
+    # search key with the properties the HIP key has: monotone in the distance, comparable across shards
+    return torch.from_numpy(best.copy()), torch.from_numpy(idx + base), torch.from_numpy(best)
+
+
+def _cpu_merge(keys, idx, dists):
+    k, i, d = keys.numpy(), idx.numpy(), dists.numpy()
+    R, B = k.shape
+    oi = np.zeros(B, dtype=np.int64)
+    o_d = np.zeros(B, dtype=np.float32)
+    for b in range(B):
+        order = sorted(range(R), key=lambda r: (k[r, b], i[r, b]))
+        oi[b], o_d[b] = i[order[0], b], d[order[0], b]
+    return torch.from_numpy(oi), torch.from_numpy(o_d)
+
+
+def _worker(rank, world, port, G, b, metric, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from deep_insight_face.parallel import ShardedGallery, shard_bounds
+        gal = gi.gallery(G, seed=3)
+        gal[G - 40:G - 10] = gal[5:35]              # equal minima living on different shards
+        probes, _ = gi.probes_from(gal, world * b, seed=4)
+        lo, hi = shard_bounds(G, world, rank)
+        sg = ShardedGallery(gal[lo:hi], lo, match_fn=_oracle_match, merge_fn=_cpu_merge)
+        idx, d = sg.match(torch.from_numpy(probes[rank * b:(rank + 1) * b]), metric)
+        np.savez(os.path.join(out_dir, 'r%d.npz' % rank), idx=idx.numpy(), d=d.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,metric', [(2, 1), (2, 0), (3, 1)])
+def test_sharded_match_equals_whole(tmp_path, world, metric):
+    G, b = 1001, 5
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, G, b, metric, str(tmp_path)), nprocs=world, join=True)
+    gal = gi.gallery(G, seed=3)
+    gal[G - 40:G - 10] = gal[5:35]
+    probes, _ = gi.probes_from(gal, world * b, seed=4)
+    want_idx, want_d, _ = od.match(probes, gal, metric)
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), 'r%d.npz' % r))
+        assert np.array_equal(z['idx'], want_idx)          # identical on every rank, first minimum wins
+        assert np.array_equal(z['d'], want_d)
+
+
+def test_shard_bounds_cover():
+    from deep_insight_face.parallel import shard_bounds
+    for G in (0, 1, 7, 8, 100_000, 1_000_003):
+        for R in (1, 2, 3, 8):
+            edges = [shard_bounds(G, R, r) for r in range(R)]
+            assert edges[0][0] == 0 and edges[-1][1] == G
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(R - 1))
+            sizes = [hi - lo for lo, hi in edges]
+            assert max(sizes) - min(sizes) <= 1
