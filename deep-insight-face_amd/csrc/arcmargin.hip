@@ -24,32 +24,26 @@ __global__ __launch_bounds__(256) void inv_norm_kernel(const float* __restrict__
   if (lane == 0) inv[r] = 1.f / sqrtf(fmaxf(s, 1e-12f));
 }
 
-template <int WM, int WN>
-__global__ __launch_bounds__(256, 2) void arcmargin_kernel(const float* __restrict__ emb, int B,
+template <class T>
+__global__ __launch_bounds__(T::NT, 2) void arcmargin_kernel(const float* __restrict__ emb, int B,
                                                            const float* __restrict__ w, int64_t C, int D,
                                                            const float* __restrict__ einv,
                                                            const float* __restrict__ winv,
                                                            const int64_t* __restrict__ labels, float s, float cm,
                                                            float sm, float th, float mm,
                                                            float* __restrict__ logits) {
-  using T = Tile<WM, WN>;
+  constexpr int WM = T::WM, WN = T::WN;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wr = T::wave_row(), wc = T::wave_col();
   const int64_t c0 = (int64_t)blockIdx.x * T::BN;
   const int b0 = blockIdx.y * T::BM;
 
   f32x16 acc[WM][WN];
-#pragma unroll
-  for (int m = 0; m < WM; ++m)
-#pragma unroll
-    for (int n = 0; n < WN; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-
-  RowLoader<T::NA> al(emb + (int64_t)b0 * D, (int64_t)B - b0, D);
-  RowLoader<T::NB> bl(w + c0 * D, C - c0, D);
-  gemm_mainloop<WM, WN>(al, bl, D / BK, smem, acc);
+  zero_acc<T>(acc);
+  RowLoader<T::NA, T::RP> al(emb + (int64_t)b0 * D, (int64_t)B - b0, D);
+  RowLoader<T::NB, T::RP> bl(w + c0 * D, C - c0, D);
+  gemm_mainloop<T>(al, bl, 0, D / BK, smem, acc);
 
 #pragma unroll
   for (int n = 0; n < WN; ++n) {
@@ -94,14 +88,14 @@ int arcmargin_run(ArcMargin* a, const float* emb, const int64_t* labels, int B, 
                      a->einv);
   DIF_HIP(hipGetLastError());
   static bool attr_set = false;
-  auto kern = arcmargin_kernel<2, 2>;
+  auto kern = arcmargin_kernel<T>;
   if (!attr_set) {
     DIF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 T::LDS_BYTES));
     attr_set = true;
   }
   dim3 grid((unsigned)((a->C + T::BN - 1) / T::BN), (unsigned)((B + T::BM - 1) / T::BM));
-  hipLaunchKernelGGL(kern, grid, dim3(256), T::LDS_BYTES, st, emb, B, a->w, a->C, a->d, a->einv, a->winv, labels,
+  hipLaunchKernelGGL(kern, grid, dim3(T::NT), T::LDS_BYTES, st, emb, B, a->w, a->C, a->d, a->einv, a->winv, labels,
                      a->s, cosf(a->m), sinf(a->m), cosf(3.14159265358979323846f - a->m),
                      sinf(3.14159265358979323846f - a->m) * a->m, logits);
   DIF_HIP(hipGetLastError());

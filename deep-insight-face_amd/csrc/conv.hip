@@ -12,6 +12,17 @@
 //       y2 = act2(v * scale2[c] + shift2[c])    (optional second output: the NEXT block's
 //                                                pre-activation BN, so it never needs a pass
 //                                                of its own)
+//   The accumulator tile is staged through LDS so that residual loads and both stores are
+//   16 bytes per lane along the channel axis (whole 512-byte rows per 32 lanes).
+//
+//   Scheduling: a persistent "stream-K" grid.  The (tile, K-step) iteration space is cut
+//   into P equal contiguous ranges, one per resident block, so every CU gets the same
+//   number of MFMA K-steps whatever the tile count (784 tiles of 128x128 over 512 resident
+//   blocks would otherwise run 2 rounds for 1.53 rounds of work).  A tile whose K range is
+//   cut is finished by the block that holds its first K-step: the other block(s) store
+//   their partial accumulators to a per-block slab and raise a flag
+//   (agent-scope release / acquire, cdna_hip_programming.md Guideline 16); the split is a
+//   pure function of the problem size, so results are run-to-run deterministic.
 //
 // The zero halo and every tile tail come from buffer-descriptor range checks (an
 // out-of-range offset loads zeros), so the loaders are branch-free.
@@ -22,15 +33,16 @@
 namespace dif {
 
 // A-operand loader: gathers BM output pixels x 32 k-values per step.
-template <int N>
+template <int N, int RP>
 struct ConvALoader {
   __amdgpu_buffer_rsrc_t rsrc;
   int32_t base[N];   // byte offset of (n - n_first, hi0, wi0, 0) relative to the tile's first image (may be < 0)
   int32_t hw0[N];    // hi0 in the high 16 bits, wi0 in the low 16 bits (biased by 0x4000 each)
   int H, W, Cin, KW, taps;
   bool fast;         // Cin % 32 == 0: one (kh, kw) per K-step, block-uniform
+  static constexpr int T_MAX_BM = 256;
 
-  __device__ __forceinline__ ConvALoader(const ConvArgs& a, int64_t m0) {
+  __device__ __forceinline__ ConvALoader(const ConvArgs& a, int m0) {
     const int tid = threadIdx.x;
     H = a.H;
     W = a.W;
@@ -39,7 +51,7 @@ struct ConvALoader {
     taps = a.KH * a.KW;
     fast = (a.Cin % BK) == 0;
     const int HoWo = a.Ho * a.Wo;
-    const int64_t n_first = (int)m0 / HoWo;
+    const int n_first = m0 / HoWo;
     const int64_t img_elems = (int64_t)a.H * a.W * a.Cin;
     const int64_t imgs_left = a.N - n_first;
     int64_t span = (T_MAX_BM + HoWo - 1) / HoWo + 1;     // images a tile can touch
@@ -47,7 +59,7 @@ struct ConvALoader {
     rsrc = make_rsrc(a.x + n_first * img_elems, (uint32_t)(span * img_elems * 4));
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-      const int m = (int)m0 + (tid >> 3) + 32 * i;
+      const int m = m0 + (tid >> 3) + RP * i;
       if (m < a.M) {
         const int n = m / HoWo;
         const int r = m - n * HoWo;
@@ -63,7 +75,6 @@ struct ConvALoader {
       }
     }
   }
-  static constexpr int T_MAX_BM = 256;
 
   __device__ __forceinline__ void load(int kstep, f32x4 (&r)[N]) const {
     int kh, kw, toff;
@@ -101,102 +112,244 @@ __device__ __forceinline__ float apply_act(float v, int act, float alpha) {
   return v;
 }
 
-template <int WM, int WN>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
-  using T = Tile<WM, WN>;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int64_t m0 = (int64_t)blockIdx.x * T::BM;
-  const int n0 = blockIdx.y * T::BN;
+__device__ __forceinline__ f32x4 load4_or(const float* p, int c, float dflt) {
+  if (p) return *reinterpret_cast<const f32x4*>(p + c);
+  return f32x4{dflt, dflt, dflt, dflt};
+}
 
-  f32x16 acc[WM][WN];
+// Stages the accumulator tile in LDS, then applies the epilogue with 16-byte accesses
+// along the channel axis.  Ends on a barrier (LDS is free afterwards).
+template <class T>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T::WM][T::WN], int m0, int n0,
+                                              float* smem) {
+  constexpr int WM = T::WM, WN = T::WN;
+  constexpr int CS = T::BN + 4;                 // LDS row pitch in floats (16-B aligned, rows shifted by 4 banks)
+  constexpr int CPR = T::BN / 4;                // float4 chunks per tile row
+  constexpr int RPP = T::NT / CPR;              // rows per pass
+  constexpr int ITER = T::BM / RPP;
+  static_assert(T::BM * CS <= T::LDS_FLOATS, "accumulator tile must fit in the staging LDS");
+  static_assert(T::NT % CPR == 0 && T::BM % RPP == 0, "epilogue mapping");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wr = T::wave_row(), wc = T::wave_col();
 #pragma unroll
   for (int m = 0; m < WM; ++m)
 #pragma unroll
     for (int n = 0; n < WN; ++n)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+      for (int r = 0; r < 16; ++r)
+        smem[((wr * WM + m) * 32 + frag_row(lane, r)) * CS + (wc * WN + n) * 32 + (lane & 31)] = acc[m][n][r];
+  __syncthreads();
 
-  ConvALoader<T::NA> al(a, m0);
-  RowLoader<T::NB> bl(a.w + (int64_t)n0 * a.Kpad, (int64_t)a.Cout - n0, a.Kpad);
-  gemm_mainloop<WM, WN>(al, bl, a.Kpad / BK, smem, acc);
-
-  const bool strided_res = a.res != nullptr && (a.res_stride != 1 || a.res_H != a.Ho || a.res_W != a.Wo);
-  const int HoWo = a.Ho * a.Wo;
+  const int c4 = tid % CPR;
+  const int r0 = tid / CPR;
+  const int c = n0 + c4 * 4;
+  if (c < a.Cout) {
+    const f32x4 sc = load4_or(a.scale, c, 1.f), sh = load4_or(a.shift, c, 0.f), al = load4_or(a.alpha, c, 0.f);
+    const f32x4 sc2 = load4_or(a.scale2, c, 1.f), sh2 = load4_or(a.shift2, c, 0.f), al2 = load4_or(a.alpha2, c, 0.f);
+    const bool strided_res = a.res != nullptr && (a.res_stride != 1 || a.res_H != a.Ho || a.res_W != a.Wo);
+    const int HoWo = a.Ho * a.Wo;
+    f32x4 rv[ITER];
+    if (a.res) {
 #pragma unroll
-  for (int n = 0; n < WN; ++n) {
-    const int c = n0 + (wc * WN + n) * 32 + (lane & 31);
-    const bool cok = c < a.Cout;
-    const int cc = cok ? c : 0;
-    const float sc = a.scale ? a.scale[cc] : 1.f;
-    const float sh = a.shift ? a.shift[cc] : 0.f;
-    const float al1 = a.alpha ? a.alpha[cc] : 0.f;
-    const float sc2 = a.scale2 ? a.scale2[cc] : 1.f;
-    const float sh2 = a.shift2 ? a.shift2[cc] : 0.f;
-    const float al2 = a.alpha2 ? a.alpha2[cc] : 0.f;
-#pragma unroll
-    for (int m = 0; m < WM; ++m) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = m0 + (wr * WM + m) * 32 + frag_row(lane, r);
-        if (row < a.M && cok) {
-          float v = fmaf(acc[m][n][r], sc, sh);
-          v = apply_act(v, a.act, al1);
-          if (a.res) {
-            int64_t ri = row;
-            if (strided_res) {
-              const int64_t img = row / HoWo;
-              const int rr = (int)(row - img * HoWo);
-              const int ho = rr / a.Wo;
-              const int wo = rr - ho * a.Wo;
-              ri = (img * a.res_H + (int64_t)ho * a.res_stride) * a.res_W + (int64_t)wo * a.res_stride;
-            }
-            v += a.res[ri * a.Cout + c];
+      for (int i = 0; i < ITER; ++i) {
+        const int row = m0 + r0 + i * RPP;
+        rv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (row < a.M) {
+          int64_t ri = row;
+          if (strided_res) {
+            const int img = row / HoWo;
+            const int rr = row - img * HoWo;
+            const int ho = rr / a.Wo;
+            const int wo = rr - ho * a.Wo;
+            ri = ((int64_t)img * a.res_H + (int64_t)ho * a.res_stride) * a.res_W + (int64_t)wo * a.res_stride;
           }
-          if (a.y) a.y[row * a.Cout + c] = v;
-          if (a.y2) a.y2[row * a.Cout + c] = apply_act(fmaf(v, sc2, sh2), a.act2, al2);
+          rv[i] = *reinterpret_cast<const f32x4*>(a.res + ri * a.Cout + c);
         }
       }
     }
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+      const int rl = r0 + i * RPP;
+      const int row = m0 + rl;
+      if (row < a.M) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(smem + rl * CS + c4 * 4);
+        f32x4 v, v2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float t = fmaf(av[j], sc[j], sh[j]);
+          t = apply_act(t, a.act, al[j]);
+          if (a.res) t += rv[i][j];
+          v[j] = t;
+          v2[j] = apply_act(fmaf(t, sc2[j], sh2[j]), a.act2, al2[j]);
+        }
+        const int64_t o = (int64_t)row * a.Cout + c;
+        if (a.y) *reinterpret_cast<f32x4*>(a.y + o) = v;
+        if (a.y2) *reinterpret_cast<f32x4*>(a.y2 + o) = v2;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// XCD-aware remap of the hardware block id: blocks b, b+8, b+16, ... share an XCD (and its
+// L2), so give each XCD one contiguous chunk of the iteration space (speed only).
+__device__ __forceinline__ int xcd_remap(int b, int P) {
+  const int q = P >> 3, r = P & 7, x = b & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
+template <class T>
+__global__ __launch_bounds__(T::NT, 2) void conv_igemm_kernel(const ConvArgs a) {
+  constexpr int WM = T::WM, WN = T::WN;
+  constexpr int SLAB = T::BM * T::BN;    // floats per partial-accumulator slab
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int* s_timeout = reinterpret_cast<int*>(smem);   // LDS is free between mainloops; no static __shared__ (G17)
+  const int tid = threadIdx.x;
+  const int P = gridDim.x;
+  const int p = xcd_remap(blockIdx.x, P);
+  const int KS = a.Kpad / BK;
+  const int tiles_n = (a.Cout + T::BN - 1) / T::BN;
+  const int tiles_m = (a.M + T::BM - 1) / T::BM;
+  const int64_t I = (int64_t)tiles_m * tiles_n * KS;
+  const int64_t beg = I * p / P, end = I * (p + 1) / P;
+
+  int64_t it = beg;
+  while (it < end) {
+    const int tile = (int)(it / KS);
+    const int kb = (int)(it - (int64_t)tile * KS);
+    const int64_t left = end - it;
+    const int ke = (KS - kb <= left) ? KS : (int)(kb + left);
+    const int mt = tile / tiles_n, nt = tile - mt * tiles_n;
+    const int m0 = mt * T::BM, n0 = nt * T::BN;
+
+    f32x16 acc[WM][WN];
+    zero_acc<T>(acc);
+    ConvALoader<T::NA, T::RP> al(a, m0);
+    RowLoader<T::NB, T::RP> bl(a.w + (int64_t)n0 * a.Kpad, (int64_t)a.Cout - n0, a.Kpad);
+    gemm_mainloop<T>(al, bl, kb, ke, smem, acc);
+
+    if (kb != 0) {
+      // not the owner of this tile: publish the partial accumulators (fragment order, 16 B per lane)
+      float* slab = a.sk_slab + (int64_t)p * SLAB;
+#pragma unroll
+      for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int n = 0; n < WN; ++n)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f32x4 v = {acc[m][n][4 * q], acc[m][n][4 * q + 1], acc[m][n][4 * q + 2], acc[m][n][4 * q + 3]};
+            *reinterpret_cast<f32x4*>(slab + (((m * WN + n) * 4 + q) * T::NT + tid) * 4) = v;
+          }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(a.sk_flag + p, a.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+      // owner: collect the rest of the K range from the blocks that follow, then finish the tile
+      int kdone = ke;
+      int q = p;
+      while (kdone < KS) {
+        ++q;
+        const int64_t qb = I * q / P, qe = I * (q + 1) / P;   // block q's range: starts inside this tile
+        const int q_kb = (int)(qb - (int64_t)tile * KS);
+        const int64_t q_len = qe - qb;
+        const int q_ke = (KS - q_kb <= q_len) ? KS : (int)(q_kb + q_len);
+        if (tid == 0) {
+          int spins = 0, timeout = 0;
+          while (__hip_atomic_load(a.sk_flag + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.sk_epoch) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1 << 18)) {
+              timeout = 1;
+              break;
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          *s_timeout = timeout;
+        }
+        __syncthreads();
+        const int timeout = *s_timeout;
+        __syncthreads();
+        if (!timeout) {
+          const float* slab = a.sk_slab + (int64_t)q * SLAB;
+#pragma unroll
+          for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int n = 0; n < WN; ++n)
+#pragma unroll
+              for (int r4 = 0; r4 < 4; ++r4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(slab + (((m * WN + n) * 4 + r4) * T::NT + tid) * 4);
+                acc[m][n][4 * r4] += v[0];
+                acc[m][n][4 * r4 + 1] += v[1];
+                acc[m][n][4 * r4 + 2] += v[2];
+                acc[m][n][4 * r4 + 3] += v[3];
+              }
+        } else {
+          // the partner never showed up (not co-resident): compute its K range here instead of
+          // waiting for ever -- slower, still correct
+          gemm_mainloop<T>(al, bl, q_kb, q_ke, smem, acc);
+        }
+        kdone = q_ke;
+      }
+      conv_epilogue<T>(a, acc, m0, n0, smem);
+    }
+    it += ke - kb;
   }
 }
 
-template <int WM, int WN>
+static int g_num_cus = 0;
+
+static int num_cus() {
+  if (g_num_cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      g_num_cus = prop.multiProcessorCount;
+    if (g_num_cus <= 0) g_num_cus = 256;
+  }
+  return g_num_cus;
+}
+
+int conv_max_blocks() { return 2 * num_cus(); }
+size_t conv_slab_floats() { return 128 * 128; }
+
+template <class T>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
-  using T = Tile<WM, WN>;
   static bool attr_set = false;
-  auto kern = conv_igemm_kernel<WM, WN>;
+  auto kern = conv_igemm_kernel<T>;
   if (!attr_set) {
     DIF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 T::LDS_BYTES));
     attr_set = true;
   }
-  dim3 grid((unsigned)((a.M + T::BM - 1) / T::BM), (unsigned)((a.Cout + T::BN - 1) / T::BN));
-  hipLaunchKernelGGL(kern, grid, dim3(256), T::LDS_BYTES, st, a);
+  const int64_t tiles = ((a.M + T::BM - 1) / T::BM) * (int64_t)((a.Cout + T::BN - 1) / T::BN);
+  const int64_t I = tiles * (a.Kpad / BK);
+  // one range per resident block; never fewer than ~4 K-steps per block
+  int64_t P = conv_max_blocks();
+  if (P > a.sk_max_blocks) P = a.sk_max_blocks;
+  if (P > (I + 3) / 4) P = (I + 3) / 4;
+  if (P < 1) P = 1;
+  hipLaunchKernelGGL(kern, dim3((unsigned)P), dim3(T::NT), T::LDS_BYTES, st, a);
   DIF_HIP(hipGetLastError());
   return 0;
 }
 
 int conv_tile_choice(int64_t M, int Cout) {
-  // 0: 128x128, 1: 128x64, 2: 64x128, 3: 64x64.  Prefer the largest tile that still
-  // yields >= ~2 blocks per CU; small layers take smaller tiles to fill the chip.
-  auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Cout + bn - 1) / bn); };
-  const int64_t want = 512;
-  if (Cout > 64) {
-    if (blocks(128, 128) >= want) return 0;
-    if (blocks(64, 128) >= want) return 2;
-    return blocks(64, 64) > blocks(64, 128) ? 3 : 2;
-  }
-  if (blocks(128, 64) >= want) return 1;
-  return 3;
+  // 0: 128x128, 1: 128x64, 2: 64x128, 3: 64x64
+  if (Cout > 64) return M > 64 ? 0 : 2;
+  return M > 64 ? 1 : 3;
 }
 
 int conv_run(const ConvArgs& a, int tile, hipStream_t st) {
   if (a.M <= 0) return 0;
   if (a.Cin % 4 != 0) return set_error("conv: Cin must be a multiple of 4 (got %d)", a.Cin);
+  if (a.Cout % 4 != 0) return set_error("conv: Cout must be a multiple of 4 (got %d)", a.Cout);
   if (a.Kpad % BK != 0) return set_error("conv: Kpad must be a multiple of %d", BK);
   if (a.H >= 0x3f00 || a.W >= 0x3f00) return set_error("conv: spatial size too large");
+  if (!a.sk_slab || !a.sk_flag || a.sk_max_blocks < 1) return set_error("conv: stream-K workspace missing");
   {
     const int64_t howo = (int64_t)a.Ho * a.Wo;
     const int64_t span = (256 + howo - 1) / howo + 1;
@@ -205,10 +358,10 @@ int conv_run(const ConvArgs& a, int tile, hipStream_t st) {
   }
   if (tile < 0) tile = conv_tile_choice(a.M, a.Cout);
   switch (tile) {
-    case 0: return launch_conv<2, 2>(a, st);
-    case 1: return launch_conv<2, 1>(a, st);
-    case 2: return launch_conv<1, 2>(a, st);
-    default: return launch_conv<1, 1>(a, st);
+    case 0: return launch_conv<Tile<2, 2>>(a, st);
+    case 1: return launch_conv<Tile<2, 1>>(a, st);
+    case 2: return launch_conv<Tile<1, 2>>(a, st);
+    default: return launch_conv<Tile<1, 1>>(a, st);
   }
 }
 

@@ -5,9 +5,9 @@
 // chain (MI355X_MICROARCH.md "Matrix cores"); peak 157.3 TFLOP/s.  This is the
 // parity path: the reference computes in float32 throughout.
 //
-// Geometry: 256 threads = 4 waves arranged 2 (M) x 2 (N); each wave owns WM x WN
-// MFMA tiles of 32x32, so the block tile is BM = 64*WM rows x BN = 64*WN columns.
-// K advances in steps of BK = 32 floats.  Operand tiles are staged
+// Geometry: WGM x WGN waves per block; each wave owns WM x WN MFMA tiles of 32x32, so
+// the block tile is BM = 32*WM*WGM rows x BN = 32*WN*WGN columns and the block has
+// 64*WGM*WGN threads.  K advances in steps of BK = 32 floats.  Operand tiles are staged
 // global -> registers -> LDS (16-byte chunks, so the A loader can synthesise the
 // zero halo of a convolution) into two LDS buffers: the loads of step k+1 are
 // issued before the MFMAs of step k and written to the other buffer after them,
@@ -15,7 +15,8 @@
 //
 // LDS image: [row][BK + 4] floats (144-byte rows).  A wave's ds_read_b128 then
 // touches 16 distinct 16-byte slots per 16-lane group (rows distinct mod 16) --
-// conflict-free; ds_write_b128 writes whole 128-byte rows per 8-lane group.
+// conflict-free (SQ_LDS_BANK_CONFLICT = 0 measured); ds_write_b128 writes whole
+// 128-byte rows per 8-lane group.
 //
 // Operand maps (cdna_hip_programming.md section 3): A lane l holds A[i = l&31][k = l>>5],
 // B lane l holds B[k = l>>5][j = l&31]; D lane l, reg r holds
@@ -30,60 +31,64 @@ namespace dif {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32;               // floats per K-step
 constexpr int LDS_STRIDE = BK + 4;   // floats per LDS row (144 B)
-constexpr int NTHREADS = 256;
 
-template <int WM, int WN>
+template <int WM_, int WN_, int WGM_ = 2, int WGN_ = 2>
 struct Tile {
-  static constexpr int BM = 64 * WM;
-  static constexpr int BN = 64 * WN;
-  static constexpr int NA = BM / 32;  // 16-B chunks of A per thread per K-step
-  static constexpr int NB = BN / 32;
+  static constexpr int WM = WM_, WN = WN_, WGM = WGM_, WGN = WGN_;
+  static constexpr int NT = 64 * WGM * WGN;       // threads per block
+  static constexpr int BM = 32 * WM * WGM;
+  static constexpr int BN = 32 * WN * WGN;
+  static constexpr int RP = NT / 8;               // rows staged per pass (8 chunks of 16 B per row)
+  static constexpr int NA = BM / RP;              // 16-B chunks of A per thread per K-step
+  static constexpr int NB = BN / RP;
   static constexpr int LDS_FLOATS = 2 * (BM + BN) * LDS_STRIDE;
   static constexpr int LDS_BYTES = LDS_FLOATS * 4;
+  static_assert(BM % RP == 0 && BN % RP == 0, "tile rows must be a multiple of the staging pass");
+  __device__ static __forceinline__ int wave_row() { return (threadIdx.x >> 6) / WGN; }
+  __device__ static __forceinline__ int wave_col() { return (threadIdx.x >> 6) % WGN; }
 };
 
 // D-fragment coordinates inside one 32x32 MFMA tile.
 __device__ __forceinline__ int frag_row(int lane, int reg) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 __device__ __forceinline__ int frag_col(int lane) { return lane & 31; }
 
+// Accumulates K-steps [kbeg, kend) into acc.  Ends on a barrier (LDS is free afterwards).
 // Loader concept:
 //   struct L { __device__ void load(int kstep, f32x4 (&r)[N]); };
-// Row i of the thread's share is tile row (tid>>3) + 32*i, chunk (tid&7) of the
+// Row i of the thread's share is tile row (tid>>3) + RP*i, chunk (tid&7) of the
 // K-step (floats 4*(tid&7) .. +3).
-template <int WM, int WN, class ALoader, class BLoader>
-__device__ __forceinline__ void gemm_mainloop(ALoader& al, BLoader& bl, int ksteps, float* lds,
-                                              f32x16 (&acc)[WM][WN]) {
-  using T = Tile<WM, WN>;
-  constexpr int BM = T::BM, BN = T::BN, NA = T::NA, NB = T::NB;
+template <class T, class ALoader, class BLoader>
+__device__ __forceinline__ void gemm_mainloop(ALoader& al, BLoader& bl, int kbeg, int kend, float* lds,
+                                              f32x16 (&acc)[T::WM][T::WN]) {
+  constexpr int WM = T::WM, WN = T::WN, BM = T::BM, BN = T::BN, NA = T::NA, NB = T::NB, RP = T::RP;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = T::wave_row(), wc = T::wave_col();
 
   constexpr int BUF = (BM + BN) * LDS_STRIDE;   // floats per LDS buffer: A rows then B rows
   constexpr int OFFB = BM * LDS_STRIDE;
 
   // staging coordinates
-  const int st_row = tid >> 3;
-  const int st_off = st_row * LDS_STRIDE + (tid & 7) * 4;
+  const int st_off = (tid >> 3) * LDS_STRIDE + (tid & 7) * 4;
   // fragment read coordinates
   const int fr_off = (lane & 31) * LDS_STRIDE + 8 * (lane >> 5);
 
   f32x4 ra[NA], rb[NB];
-  al.load(0, ra);
-  bl.load(0, rb);
+  al.load(kbeg, ra);
+  bl.load(kbeg, rb);
 #pragma unroll
-  for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(lds + st_off + i * 32 * LDS_STRIDE) = ra[i];
+  for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(lds + st_off + i * RP * LDS_STRIDE) = ra[i];
 #pragma unroll
-  for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(lds + OFFB + st_off + i * 32 * LDS_STRIDE) = rb[i];
+  for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(lds + OFFB + st_off + i * RP * LDS_STRIDE) = rb[i];
   __syncthreads();
 
-  for (int ks = 0; ks < ksteps; ++ks) {
-    const int cur = ks & 1;
-    const bool more = (ks + 1 < ksteps);
+  for (int ks = kbeg; ks < kend; ++ks) {
+    const int cur = (ks - kbeg) & 1;
+    const bool more = (ks + 1 < kend);
     if (more) {
       al.load(ks + 1, ra);
       bl.load(ks + 1, rb);
@@ -119,15 +124,23 @@ __device__ __forceinline__ void gemm_mainloop(ALoader& al, BLoader& bl, int kste
       float* wa = lds + (cur ^ 1) * BUF + st_off;
       float* wb = lds + (cur ^ 1) * BUF + OFFB + st_off;
 #pragma unroll
-      for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(wa + i * 32 * LDS_STRIDE) = ra[i];
+      for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(wa + i * RP * LDS_STRIDE) = ra[i];
 #pragma unroll
-      for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(wb + i * 32 * LDS_STRIDE) = rb[i];
+      for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(wb + i * RP * LDS_STRIDE) = rb[i];
     }
     __syncthreads();
   }
 }
 
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <class T>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[T::WM][T::WN]) {
+#pragma unroll
+  for (int m = 0; m < T::WM; ++m)
+#pragma unroll
+    for (int n = 0; n < T::WN; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+}
 
 // Buffer resource over [base, base + bytes): loads past the end return zeros, which is
 // how tile tails and the zero halo of a convolution are produced without branches.
@@ -145,14 +158,14 @@ constexpr uint32_t OOB = 0xFFFFFFF0u;   // byte offset guaranteed past any descr
 // convolution weights ([Cout][Kpad]), the gallery, the probes and the ArcMargin class
 // centres.  `base` points at the tile's first row (block-uniform), so byte offsets stay
 // below 2^32 for any tile; ld is a multiple of 4 and K is padded to a multiple of BK.
-template <int N>
+template <int N, int RP>
 struct RowLoader {
   __amdgpu_buffer_rsrc_t rsrc;
   uint32_t off0;   // byte offset of (row = tid>>3, k = 4*(tid&7)) inside the tile
   uint32_t ldb;    // row pitch in bytes
   __device__ __forceinline__ RowLoader(const float* tile_base, int64_t rows_left, int ld) {
     const int tid = threadIdx.x;
-    const int64_t rows = rows_left < 32 * N ? rows_left : 32 * N;
+    const int64_t rows = rows_left < RP * N ? rows_left : RP * N;
     rsrc = make_rsrc(tile_base, (uint32_t)(rows * ld * 4));
     ldb = (uint32_t)ld * 4u;
     off0 = (uint32_t)(tid >> 3) * ldb + (uint32_t)(tid & 7) * 16u;
@@ -160,7 +173,7 @@ struct RowLoader {
   __device__ __forceinline__ void load(int kstep, f32x4 (&r)[N]) const {
     const uint32_t o = off0 + (uint32_t)kstep * (BK * 4);
 #pragma unroll
-    for (int i = 0; i < N; ++i) r[i] = buf_load4(rsrc, o + (uint32_t)i * 32u * ldb);
+    for (int i = 0; i < N; ++i) r[i] = buf_load4(rsrc, o + (uint32_t)i * RP * ldb);
   }
 };
 

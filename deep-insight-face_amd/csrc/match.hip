@@ -22,16 +22,16 @@ __device__ __forceinline__ bool better(float k, int i, float bk, int bi) {
   return (k < bk) || (k == bk && i < bi);
 }
 
-template <int WM, int WN>
-__global__ __launch_bounds__(256, 2) void match_tile_kernel(const float* __restrict__ gallery, int64_t G,
+template <class T>
+__global__ __launch_bounds__(T::NT, 2) void match_tile_kernel(const float* __restrict__ gallery, int64_t G,
                                                             const float* __restrict__ probes, int B, int D,
                                                             const float* __restrict__ aux, int metric,
                                                             float* __restrict__ part_key,
                                                             int* __restrict__ part_idx) {
-  using T = Tile<WM, WN>;
+  constexpr int WM = T::WM, WN = T::WN;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wr = T::wave_row(), wc = T::wave_col();
   const int p0 = blockIdx.y * T::BN;
   const int ksteps = D / BK;
   const int64_t gtiles = (G + T::BM - 1) / T::BM;
@@ -47,16 +47,10 @@ __global__ __launch_bounds__(256, 2) void match_tile_kernel(const float* __restr
   for (int64_t gt = blockIdx.x; gt < gtiles; gt += gridDim.x) {
     const int64_t g0 = gt * T::BM;
     f32x16 acc[WM][WN];
-#pragma unroll
-    for (int m = 0; m < WM; ++m)
-#pragma unroll
-      for (int n = 0; n < WN; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-
-    RowLoader<T::NA> al(gallery + g0 * D, G - g0, D);
-    RowLoader<T::NB> bl(probes + (int64_t)p0 * D, (int64_t)B - p0, D);
-    gemm_mainloop<WM, WN>(al, bl, ksteps, smem, acc);
+    zero_acc<T>(acc);
+    RowLoader<T::NA, T::RP> al(gallery + g0 * D, G - g0, D);
+    RowLoader<T::NB, T::RP> bl(probes + (int64_t)p0 * D, (int64_t)B - p0, D);
+    gemm_mainloop<T>(al, bl, 0, ksteps, smem, acc);
 
     // aux[g] = -1/|g| (metric 1) or |g|^2 (metric 0); rows past G read 0 through the
     // descriptor and are masked out of the search.
@@ -99,15 +93,15 @@ __global__ __launch_bounds__(256, 2) void match_tile_kernel(const float* __restr
       bidx[n] = oi;
     }
   }
-  // waves wr = 0 / 1 share probe columns: merge through LDS (the mainloop ended on a barrier)
-  float* skey = smem;
-  int* sidx = reinterpret_cast<int*>(smem + T::BN);
-  if (wr == 1 && lane < 32) {
+  // the WGM waves of a column share probe columns: merge through LDS (the mainloop ended on a barrier)
+  float* skey = smem;                                             // [WGM][BN]
+  int* sidx = reinterpret_cast<int*>(smem + T::WGM * T::BN);      // [WGM][BN]
+  if (lane < 32) {
 #pragma unroll
     for (int n = 0; n < WN; ++n) {
       const int c = (wc * WN + n) * 32 + lane;
-      skey[c] = bkey[n];
-      sidx[c] = bidx[n];
+      skey[wr * T::BN + c] = bkey[n];
+      sidx[wr * T::BN + c] = bidx[n];
     }
   }
   __syncthreads();
@@ -115,11 +109,14 @@ __global__ __launch_bounds__(256, 2) void match_tile_kernel(const float* __restr
 #pragma unroll
     for (int n = 0; n < WN; ++n) {
       const int c = (wc * WN + n) * 32 + lane;
-      const float ok = skey[c];
-      const int oi = sidx[c];
-      if (better(ok, oi, bkey[n], bidx[n])) {
-        bkey[n] = ok;
-        bidx[n] = oi;
+#pragma unroll
+      for (int w = 1; w < T::WGM; ++w) {
+        const float ok = skey[w * T::BN + c];
+        const int oi = sidx[w * T::BN + c];
+        if (better(ok, oi, bkey[n], bidx[n])) {
+          bkey[n] = ok;
+          bidx[n] = oi;
+        }
       }
       const int p = p0 + c;
       if (p < B) {
@@ -263,19 +260,18 @@ using namespace dif;
 
 namespace dif {
 
-template <int WM, int WN>
+template <class T>
 static int launch_match_tiles(const Gallery* g, const float* probes, int B, int metric, int nparts,
                               hipStream_t st) {
-  using T = Tile<WM, WN>;
   static bool attr_set = false;
-  auto kern = match_tile_kernel<WM, WN>;
+  auto kern = match_tile_kernel<T>;
   if (!attr_set) {
     DIF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 T::LDS_BYTES));
     attr_set = true;
   }
   dim3 grid(nparts, (B + T::BN - 1) / T::BN);
-  hipLaunchKernelGGL(kern, grid, dim3(256), T::LDS_BYTES, st, g->rows, g->n, probes, B, g->d,
+  hipLaunchKernelGGL(kern, grid, dim3(T::NT), T::LDS_BYTES, st, g->rows, g->n, probes, B, g->d,
                      metric == 1 ? g->ninv : g->sq, metric, g->part_key, g->part_idx);
   DIF_HIP(hipGetLastError());
   return 0;
@@ -310,9 +306,9 @@ int match_run(Gallery* g, const float* probes, int B, int metric, int64_t* idx_o
   }
   int rc;
   if (B <= 64)
-    rc = launch_match_tiles<2, 1>(g, probes, B, metric, nparts, st);
+    rc = launch_match_tiles<Tile<2, 1>>(g, probes, B, metric, nparts, st);
   else
-    rc = launch_match_tiles<2, 2>(g, probes, B, metric, nparts, st);
+    rc = launch_match_tiles<Tile<2, 2>>(g, probes, B, metric, nparts, st);
   if (rc) return rc;
   hipLaunchKernelGGL(match_finish_kernel, dim3(B), dim3(64), 0, st, g->part_key, g->part_idx, nparts, B, probes,
                      g->rows, g->d, metric, g->index_base, idx_out, dist_out, key_out);

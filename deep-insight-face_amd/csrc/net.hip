@@ -480,6 +480,18 @@ int Net::finalize(int mb) {
           free_list.push_back(tensors[t].buf);
       }
   }
+  sk_max_blocks = conv_max_blocks();
+  {
+    void* d = nullptr;
+    DIF_HIP(hipMalloc(&d, (size_t)sk_max_blocks * conv_slab_floats() * sizeof(float)));
+    allocs.push_back(d);
+    sk_slab = static_cast<float*>(d);
+    DIF_HIP(hipMalloc(&d, (size_t)sk_max_blocks * sizeof(unsigned)));
+    allocs.push_back(d);
+    sk_flag = static_cast<unsigned*>(d);
+    DIF_HIP(hipMemset(sk_flag, 0, (size_t)sk_max_blocks * sizeof(unsigned)));
+    sk_epoch = 0;
+  }
   bufs.assign(buf_elems.size(), nullptr);
   for (size_t b = 0; b < buf_elems.size(); ++b) {
     float* d = nullptr;
@@ -500,8 +512,8 @@ const char* Net::kernel_name(const Op& op, int n) const {
     case OP_L2NORM: return "l2norm_kernel";
     case OP_CONV: {
       const TensorDesc& yd = tensors[op.y >= 0 ? op.y : op.y2];
-      static const char* names[4] = {"conv_igemm_kernel<2,2>", "conv_igemm_kernel<2,1>", "conv_igemm_kernel<1,2>",
-                                     "conv_igemm_kernel<1,1>"};
+      static const char* names[4] = {"conv_igemm_kernel<128x128>", "conv_igemm_kernel<128x64>",
+                                     "conv_igemm_kernel<64x128>", "conv_igemm_kernel<64x64>"};
       return names[conv_tile_choice((int64_t)n * yd.H * yd.W, op.Cout)];
     }
   }
@@ -587,6 +599,10 @@ int Net::embed(const void* xin, int n, int layout, int dtype, float* out, hipStr
           a.res_W = yd.W;
           a.res_stride = 1;
         }
+        a.sk_slab = sk_slab;
+        a.sk_flag = sk_flag;
+        a.sk_max_blocks = sk_max_blocks;
+        a.sk_epoch = ++sk_epoch;
         if (conv_run(a, -1, st)) return -1;
         break;
       }

@@ -79,6 +79,10 @@ struct Net {
   std::vector<void*> allocs;
   std::vector<float*> bufs;
   std::vector<int64_t> buf_elems;   // per image
+  float* sk_slab = nullptr;         // stream-K workspace of the conv kernel
+  unsigned* sk_flag = nullptr;
+  int sk_max_blocks = 0;
+  unsigned sk_epoch = 0;
 
   ~Net();
   int build();                       // dispatch on arch/head

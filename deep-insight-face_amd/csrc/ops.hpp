@@ -24,8 +24,16 @@ struct ConvArgs {
   int M;                // N*Ho*Wo
   int act, act2;
   int res_H, res_W, res_stride;
+  // stream-K workspace (owned by the caller): one partial-accumulator slab and one flag per
+  // persistent block; sk_epoch is unique per launch so flags never need clearing
+  float* sk_slab;
+  unsigned* sk_flag;
+  unsigned sk_epoch;
+  int sk_max_blocks;
 };
 
+int conv_max_blocks();        // persistent blocks the kernel may use on this device
+size_t conv_slab_floats();    // floats per slab
 int conv_tile_choice(int64_t M, int Cout);
 int conv_run(const ConvArgs& a, int tile, hipStream_t st);
 

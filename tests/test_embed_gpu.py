@@ -105,9 +105,12 @@ def test_input_forms_agree(cuda):
     model.set_input_transform()
     assert cosine_gap(fused, base).max() < 1e-6
     assert np.array_equal(fused, fused_nchw)
-    # batch invariance and determinism: a row's embedding does not depend on its batch
+    # a row's embedding does not depend on its batch beyond float32 rounding (the stream-K
+    # split points of a convolution move with the batch size, which reorders a few sums) ...
     one = model.predict_on_batch(x[2:3])
-    assert np.array_equal(one[0], base[2])
+    assert cosine_gap(one, base[2:3]).max() < 1e-6
+    np.testing.assert_allclose(one[0], base[2], atol=2e-6)
+    # ... and the same batch gives bit-identical results run to run
     assert np.array_equal(model.predict_on_batch(x), base)
     with pytest.raises(ValueError):
         model.predict_on_batch(np.zeros((2, 96, 96, 3), dtype=np.float32))
