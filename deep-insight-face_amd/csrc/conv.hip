@@ -258,10 +258,10 @@ __global__ __launch_bounds__(T::NT, 2) void conv_igemm_kernel(const ConvArgs a) 
         const int64_t q_len = qe - qb;
         const int q_ke = (KS - q_kb <= q_len) ? KS : (int)(q_kb + q_len);
         if (tid == 0) {
-          int spins = 0, timeout = 0;
-          while (__hip_atomic_load(a.sk_flag + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.sk_epoch) {
+          int spins = 0, timeout = a.sk_spin_limit < 0 ? 1 : 0;
+          while (!timeout && __hip_atomic_load(a.sk_flag + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.sk_epoch) {
             __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1 << 18)) {
+            if (++spins > a.sk_spin_limit) {
               timeout = 1;
               break;
             }

@@ -15,6 +15,7 @@
 #include "net.hpp"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -491,6 +492,7 @@ int Net::finalize(int mb) {
     sk_flag = static_cast<unsigned*>(d);
     DIF_HIP(hipMemset(sk_flag, 0, (size_t)sk_max_blocks * sizeof(unsigned)));
     sk_epoch = 0;
+    if (const char* e = getenv("DIF_SK_SPIN_LIMIT")) sk_spin_limit = atoi(e);   // test hook (tests/test_embed_gpu.py)
   }
   bufs.assign(buf_elems.size(), nullptr);
   for (size_t b = 0; b < buf_elems.size(); ++b) {
@@ -603,6 +605,7 @@ int Net::embed(const void* xin, int n, int layout, int dtype, float* out, hipStr
         a.sk_flag = sk_flag;
         a.sk_max_blocks = sk_max_blocks;
         a.sk_epoch = ++sk_epoch;
+        a.sk_spin_limit = sk_spin_limit;
         if (conv_run(a, -1, st)) return -1;
         break;
       }

@@ -83,6 +83,7 @@ struct Net {
   unsigned* sk_flag = nullptr;
   int sk_max_blocks = 0;
   unsigned sk_epoch = 0;
+  int sk_spin_limit = 1 << 18;
 
   ~Net();
   int build();                       // dispatch on arch/head

@@ -30,6 +30,7 @@ struct ConvArgs {
   unsigned* sk_flag;
   unsigned sk_epoch;
   int sk_max_blocks;
+  int sk_spin_limit;    // polls before the owner computes a missing K range itself; < 0: always (test hook)
 };
 
 int conv_max_blocks();        // persistent blocks the kernel may use on this device

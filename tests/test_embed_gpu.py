@@ -164,3 +164,22 @@ def test_arcmargin_vs_oracle(cuda):
         np.testing.assert_allclose(gotm, wantm, atol=64 * 2e-5)
         assert np.array_equal(np.argmax(got, 1), np.argmax(want, 1))
         head.close()
+
+
+def test_streamk_fallback_branch(cuda, monkeypatch):
+    """The stream-K owner normally adds its partners' partial slabs; if a partner is not
+    co-resident it recomputes the missing K range itself.  That branch is rare and
+    scheduling-dependent, so force it (DIF_SK_SPIN_LIMIT=-1) and check parity again
+    (cdna_hip_programming.md rule 26: a rare branch needs its own test)."""
+    monkeypatch.setenv('DIF_SK_SPIN_LIMIT', '-1')
+    model, p = build('iresnet50', 'v2', 512, max_batch=3)
+    x = scaled(crops_u8(3, seed=77))
+    got = model.predict_on_batch(x)
+    monkeypatch.delenv('DIF_SK_SPIN_LIMIT')
+    want = nets.embed(x, p, 'iresnet50', 512, 'v2')
+    assert cosine_gap(got, want).max() < TOL
+    ref_model, _ = build('iresnet50', 'v2', 512, max_batch=3)
+    normal = ref_model.predict_on_batch(x)
+    assert cosine_gap(got, normal).max() < 1e-6
+    model.close()
+    ref_model.close()

@@ -1,0 +1,77 @@
+"""Two ranks sharing the one GPU of the test box run the whole sharded pipeline with the
+real HIP kernels: per-rank embed -> all-gather -> gallery-sharded dif_match -> all-gather
+of partials -> dif_match_merge.  gloo carries the collectives here (RCCL needs one GPU per
+rank); the data path and every kernel are the ones bench.py --gpus N uses."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import golden_inputs as gi
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _CpuCollectives:
+    """all_gather_into_tensor for CUDA tensors over gloo: stage through the host."""
+
+    def __init__(self):
+        self._orig = dist.all_gather_into_tensor
+
+    def __call__(self, out, inp, group=None):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        self._orig(o, inp.cpu(), group=group)
+        out.copy_(o)
+
+
+def _worker(rank, world, port, G, b, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        dist.all_gather_into_tensor = _CpuCollectives()
+        from deep_insight_face.parallel import ShardedGallery, shard_bounds
+        gal = gi.gallery(G, seed=3)
+        gal[G - 40:G - 10] = gal[5:35]
+        probes, _ = gi.probes_from(gal, world * b, seed=4)
+        lo, hi = shard_bounds(G, world, rank)
+        sg = ShardedGallery(torch.from_numpy(gal[lo:hi]).cuda(), lo)
+        res = {}
+        for m in (0, 1):
+            idx, d = sg.match(torch.from_numpy(probes[rank * b:(rank + 1) * b]).cuda(), m)
+            res['idx%d' % m], res['d%d' % m] = idx.cpu().numpy(), d.cpu().numpy()
+        np.savez(os.path.join(out_dir, 'r%d.npz' % rank), **res)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu(cuda, tmp_path):
+    from oracle import distance as od
+    world, G, b = 2, 3001, 37
+    mp.spawn(_worker, args=(world, _free_port(), G, b, str(tmp_path)), nprocs=world, join=True)
+    gal = gi.gallery(G, seed=3)
+    gal[G - 40:G - 10] = gal[5:35]
+    probes, _ = gi.probes_from(gal, world * b, seed=4)
+    for m in (0, 1):
+        want_idx, want_d, _ = od.match(probes, gal, m)
+        for r in range(world):
+            z = np.load(os.path.join(str(tmp_path), 'r%d.npz' % r))
+            assert np.array_equal(z['idx%d' % m], want_idx)
+            if m == 0:
+                np.testing.assert_allclose(z['d%d' % m], want_d, atol=1e-5)
+            else:
+                np.testing.assert_allclose(np.cos(z['d%d' % m].astype(np.float64) * np.pi),
+                                           np.cos(want_d.astype(np.float64) * np.pi), atol=1e-5)
