@@ -48,6 +48,17 @@ def synthetic_gallery(rows, d, seed, device):
     return torch.nn.functional.normalize(x, dim=1).to(device)
 
 
+def measured_traffic(workload, batch):
+    """HBM bytes per forward of the conv kernels from the committed rocprofv3 PMC passes
+    (FETCH_SIZE doubled + WRITE_SIZE, tools/pmc_traffic.py).  Counters cannot be read from
+    inside the process, so this is the profile of the same command, or None."""
+    path = os.path.join(ROOT, 'profiles', 'r01_%s_b256_hbm_traffic.json' % workload)
+    if batch != 256 or not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        return json.load(fh)['total']['conv_hbm_bytes_per_forward']
+
+
 def cpu_baseline(arch, head, gallery_rows, sample=16):
     """The oracle (NumPy port of the reference's algorithm) on a bounded sample of the same
     workload: `sample` faces embedded with the same synthetic weights + matched against the
@@ -184,7 +195,8 @@ def main():
                                            '%d conv launches of one %s forward at batch %d)'
                                            % (sum(1 for _, k, _, _ in prof if k.startswith('conv_igemm')), arch, batch),
                 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': measured_traffic(args.workload, batch),
+                'traffic_unit': 'HBM bytes per forward (rocprofv3 PMC, profiles/)',
                 'algorithmic_flops_per_forward': flops_embed,
                 'forward_ms_hip_events': embed_ms,
                 'conv_only': {'ms': conv_ms, 'tflops': conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms else None},
