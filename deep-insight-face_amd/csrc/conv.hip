@@ -30,6 +30,8 @@
 #include "dif_internal.hpp"
 #include "ops.hpp"
 
+#include <stdlib.h>
+
 namespace dif {
 
 // A-operand loader: gathers BM output pixels x 32 k-values per step.
@@ -39,6 +41,7 @@ struct ConvALoader {
   int32_t base[N];   // byte offset of (n - n_first, hi0, wi0, 0) relative to the tile's first image (may be < 0)
   int32_t hw0[N];    // hi0 in the high 16 bits, wi0 in the low 16 bits (biased by 0x4000 each)
   int H, W, Cin, KW, taps;
+  FastDiv fd_cin, fd_kw;
   bool fast;         // Cin % 32 == 0: one (kh, kw) per K-step, block-uniform
   static constexpr int T_MAX_BM = 256;
 
@@ -51,7 +54,9 @@ struct ConvALoader {
     taps = a.KH * a.KW;
     fast = (a.Cin % BK) == 0;
     const int HoWo = a.Ho * a.Wo;
-    const int n_first = m0 / HoWo;
+    fd_cin = a.fd_cin;
+    fd_kw = a.fd_kw;
+    const int n_first = a.fd_howo.div(m0);
     const int64_t img_elems = (int64_t)a.H * a.W * a.Cin;
     const int64_t imgs_left = a.N - n_first;
     int64_t span = (T_MAX_BM + HoWo - 1) / HoWo + 1;     // images a tile can touch
@@ -61,10 +66,9 @@ struct ConvALoader {
     for (int i = 0; i < N; ++i) {
       const int m = m0 + (tid >> 3) + RP * i;
       if (m < a.M) {
-        const int n = m / HoWo;
-        const int r = m - n * HoWo;
-        const int ho = r / a.Wo;
-        const int wo = r - ho * a.Wo;
+        int n, r, ho, wo;
+        a.fd_howo.divmod(m, n, r);
+        a.fd_wo.divmod(r, ho, wo);
         const int hi0 = ho * a.stride - a.pad_t;
         const int wi0 = wo * a.stride - a.pad_l;
         base[i] = (int32_t)((((int64_t)(n - n_first) * a.H + hi0) * a.W + wi0) * a.Cin * 4) + (tid & 7) * 16;
@@ -80,18 +84,14 @@ struct ConvALoader {
     int kh, kw, toff;
     bool tap_ok = true;
     if (fast) {
-      const int k0 = kstep * BK;
-      const int tap = k0 / Cin;
-      const int ci0 = k0 - tap * Cin;
-      kh = tap / KW;
-      kw = tap - kh * KW;
+      int tap, ci0;
+      fd_cin.divmod(kstep * BK, tap, ci0);
+      fd_kw.divmod(tap, kh, kw);
       toff = ((kh * W + kw) * Cin + ci0) * 4;
     } else {
-      const int k = kstep * BK + (threadIdx.x & 7) * 4;
-      const int tap = k / Cin;
-      const int ci = k - tap * Cin;
-      kh = tap / KW;
-      kw = tap - kh * KW;
+      int tap, ci;
+      fd_cin.divmod(kstep * BK + (threadIdx.x & 7) * 4, tap, ci);
+      fd_kw.divmod(tap, kh, kw);
       tap_ok = tap < taps;
       toff = ((kh * W + kw) * Cin + ci) * 4 - (threadIdx.x & 7) * 16;
     }
@@ -210,16 +210,16 @@ __global__ __launch_bounds__(T::NT, 2) void conv_igemm_kernel(const ConvArgs a) 
   const int KS = a.Kpad / BK;
   const int tiles_n = (a.Cout + T::BN - 1) / T::BN;
   const int tiles_m = (a.M + T::BM - 1) / T::BM;
-  const int64_t I = (int64_t)tiles_m * tiles_n * KS;
-  const int64_t beg = I * p / P, end = I * (p + 1) / P;
+  const int I = tiles_m * tiles_n * KS;                       // < 2^31 (checked by conv_run)
+  const int beg = (int)((int64_t)I * p / P), end = (int)((int64_t)I * (p + 1) / P);
 
-  int64_t it = beg;
+  int it = beg;
   while (it < end) {
-    const int tile = (int)(it / KS);
-    const int kb = (int)(it - (int64_t)tile * KS);
-    const int64_t left = end - it;
-    const int ke = (KS - kb <= left) ? KS : (int)(kb + left);
-    const int mt = tile / tiles_n, nt = tile - mt * tiles_n;
+    int tile, kb, mt, nt;
+    a.fd_ks.divmod(it, tile, kb);
+    const int left = end - it;
+    const int ke = (KS - kb <= left) ? KS : kb + left;
+    a.fd_tiles_n.divmod(tile, mt, nt);
     const int m0 = mt * T::BM, n0 = nt * T::BN;
 
     f32x16 acc[WM][WN];
@@ -253,10 +253,10 @@ __global__ __launch_bounds__(T::NT, 2) void conv_igemm_kernel(const ConvArgs a) 
       int q = p;
       while (kdone < KS) {
         ++q;
-        const int64_t qb = I * q / P, qe = I * (q + 1) / P;   // block q's range: starts inside this tile
-        const int q_kb = (int)(qb - (int64_t)tile * KS);
-        const int64_t q_len = qe - qb;
-        const int q_ke = (KS - q_kb <= q_len) ? KS : (int)(q_kb + q_len);
+        const int qb = (int)((int64_t)I * q / P), qe = (int)((int64_t)I * (q + 1) / P);   // starts inside this tile
+        const int q_kb = qb - tile * KS;
+        const int q_len = qe - qb;
+        const int q_ke = (KS - q_kb <= q_len) ? KS : q_kb + q_len;
         if (tid == 0) {
           int spins = 0, timeout = a.sk_spin_limit < 0 ? 1 : 0;
           while (!timeout && __hip_atomic_load(a.sk_flag + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.sk_epoch) {
@@ -313,7 +313,7 @@ static int num_cus() {
   return g_num_cus;
 }
 
-int conv_max_blocks() { return 2 * num_cus(); }
+int conv_max_blocks() { return 4 * num_cus(); }
 size_t conv_slab_floats() { return 128 * 128; }
 
 template <class T>
@@ -326,21 +326,52 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
     attr_set = true;
   }
   const int64_t tiles = ((a.M + T::BM - 1) / T::BM) * (int64_t)((a.Cout + T::BN - 1) / T::BN);
-  const int64_t I = tiles * (a.Kpad / BK);
-  // one range per resident block; never fewer than ~4 K-steps per block
-  int64_t P = conv_max_blocks();
-  if (P > a.sk_max_blocks) P = a.sk_max_blocks;
-  if (P > (I + 3) / 4) P = (I + 3) / 4;
+  const int KS = a.Kpad / BK;
+  const int64_t I = tiles * KS;
+  if (I >= 0x7fffffffLL) return set_error("conv: iteration space too large");
+  // Resident blocks for this tile shape (LDS-limited: 2 per CU, 4 for the 64x64 tile).
+  int64_t slots = (T::LDS_BYTES * 4 <= 160 * 1024 ? 4 : 2) * (int64_t)num_cus();
+  if (slots > a.sk_max_blocks) slots = a.sk_max_blocks;
+  // Many tiles, or a short K loop (< 33 steps: a split tile's slab hand-off would cost more
+  // than the imbalance it removes -- measured): one whole tile per block, the hardware
+  // dispatcher balances them and no tile is ever split.  Few long tiles: stream-K, one equal
+  // K-step range per resident block.
+  int64_t P;
+  static const int sk_min_ks = getenv("DIF_SK_MIN_KS") ? atoi(getenv("DIF_SK_MIN_KS")) : 33;
+  if (tiles >= 8 * slots || KS < sk_min_ks) {
+    P = tiles;
+  } else {
+    P = slots;
+    if (P > (I + 3) / 4) P = (I + 3) / 4;
+  }
   if (P < 1) P = 1;
-  hipLaunchKernelGGL(kern, dim3((unsigned)P), dim3(T::NT), T::LDS_BYTES, st, a);
+  ConvArgs b = a;
+  b.fd_howo = make_fastdiv(a.Ho * a.Wo);
+  b.fd_wo = make_fastdiv(a.Wo);
+  b.fd_cin = make_fastdiv(a.Cin);
+  b.fd_kw = make_fastdiv(a.KW);
+  b.fd_ks = make_fastdiv(KS);
+  b.fd_tiles_n = make_fastdiv((a.Cout + T::BN - 1) / T::BN);
+  hipLaunchKernelGGL(kern, dim3((unsigned)P), dim3(T::NT), T::LDS_BYTES, st, b);
   DIF_HIP(hipGetLastError());
   return 0;
 }
 
-int conv_tile_choice(int64_t M, int Cout) {
+int conv_tile_choice(int64_t M, int Cout, int Kpad) {
   // 0: 128x128, 1: 128x64, 2: 64x128, 3: 64x64
-  if (Cout > 64) return M > 64 ? 0 : 2;
-  return M > 64 ? 1 : 3;
+  static const int forced = getenv("DIF_CONV_TILE") ? atoi(getenv("DIF_CONV_TILE")) : -1;
+  static const int small_k = getenv("DIF_SMALLK") ? atoi(getenv("DIF_SMALLK")) : 0;
+  if (forced >= 0) return (Cout <= 64 && (forced == 0 || forced == 2)) ? forced + 1 : forced;
+  (void)small_k;
+  (void)M;
+  (void)Cout;
+  (void)Kpad;
+  // Measured on MI355X (tools/layer_profile.py with DIF_CONV_TILE=0..3, both networks at
+  // batch 256): the 64x64 tile wins or ties on every layer class -- four blocks per CU keep
+  // the MFMA pipe fed across each block's barriers, prologue and epilogue, and the hardware
+  // dispatcher balances the many small tiles; the larger tiles only tie on the long-K,
+  // wide-N layers.  The larger shapes stay available for experiments (DIF_CONV_TILE).
+  return 3;
 }
 
 int conv_run(const ConvArgs& a, int tile, hipStream_t st) {
@@ -356,7 +387,7 @@ int conv_run(const ConvArgs& a, int tile, hipStream_t st) {
     if (span * a.H * a.W * a.Cin * 4 >= 0x7fffffffLL)
       return set_error("conv: a 256-pixel tile spans more than 2 GiB of input (%dx%dx%d)", a.H, a.W, a.Cin);
   }
-  if (tile < 0) tile = conv_tile_choice(a.M, a.Cout);
+  if (tile < 0) tile = conv_tile_choice(a.M, a.Cout, a.Kpad);
   switch (tile) {
     case 0: return launch_conv<Tile<2, 2>>(a, st);
     case 1: return launch_conv<Tile<2, 1>>(a, st);

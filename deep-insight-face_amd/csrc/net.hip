@@ -516,7 +516,7 @@ const char* Net::kernel_name(const Op& op, int n) const {
       const TensorDesc& yd = tensors[op.y >= 0 ? op.y : op.y2];
       static const char* names[4] = {"conv_igemm_kernel<128x128>", "conv_igemm_kernel<128x64>",
                                      "conv_igemm_kernel<64x128>", "conv_igemm_kernel<64x64>"};
-      return names[conv_tile_choice((int64_t)n * yd.H * yd.W, op.Cout)];
+      return names[conv_tile_choice((int64_t)n * yd.H * yd.W, op.Cout, (op.KH * op.KW * op.Cin + 31) / 32 * 32)];
     }
   }
   return "?";

@@ -7,6 +7,37 @@ namespace dif {
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_PRELU = 2 };
 
+// Division of a non-negative int (< 2^31) by a launch-invariant divisor: one mul-hi and a
+// shift instead of the ~40-instruction expansion of a runtime integer division.
+struct FastDiv {
+  uint32_t mul, shift, d;
+#if defined(__HIPCC__)
+  __device__ __forceinline__ int div(int n) const {
+    return d == 1 ? n : (int)(__umulhi((uint32_t)n, mul) >> shift);
+  }
+  __device__ __forceinline__ void divmod(int n, int& q, int& r) const {
+    q = div(n);
+    r = n - q * (int)d;
+  }
+#endif
+};
+inline FastDiv make_fastdiv(int d) {
+  FastDiv f;
+  f.d = (uint32_t)d;
+  if (d <= 1) {
+    f.mul = 0;
+    f.shift = 0;
+    f.d = 1;
+    return f;
+  }
+  int lg = 0;
+  while ((1u << lg) < (uint32_t)d) ++lg;        // ceil(log2 d)
+  const unsigned p = 31 + lg;
+  f.mul = (uint32_t)(((1ull << p) + (uint32_t)d - 1) / (uint32_t)d);
+  f.shift = p - 32;
+  return f;
+}
+
 struct ConvArgs {
   const float* x;       // [N,H,W,Cin] NHWC
   const float* w;       // packed [Cout][Kpad], k = (kh*KW + kw)*Cin + ci, zero padded
@@ -31,11 +62,13 @@ struct ConvArgs {
   unsigned sk_epoch;
   int sk_max_blocks;
   int sk_spin_limit;    // polls before the owner computes a missing K range itself; < 0: always (test hook)
+  // launch-invariant divisors (filled by conv_run)
+  FastDiv fd_howo, fd_wo, fd_cin, fd_kw, fd_ks, fd_tiles_n;
 };
 
 int conv_max_blocks();        // persistent blocks the kernel may use on this device
 size_t conv_slab_floats();    // floats per slab
-int conv_tile_choice(int64_t M, int Cout);
+int conv_tile_choice(int64_t M, int Cout, int Kpad);
 int conv_run(const ConvArgs& a, int tile, hipStream_t st);
 
 struct PoolArgs {

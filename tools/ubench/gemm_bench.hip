@@ -71,7 +71,10 @@ int main(int argc, char** argv) {
                     {50176, 256, 2304, "iresnet stage3 3x3 @B=256"},
                     {200704, 128, 1152, "iresnet stage2 3x3 @B=256"},
                     {802816, 64, 576, "iresnet stage1 3x3 @B=256"},
-                    {12544, 512, 4608, "iresnet stage4 3x3 @B=256"}};
+                    {12544, 512, 4608, "iresnet stage4 3x3 @B=256"},
+                    {200704, 256, 64, "resnet50v2 stage2 _3_conv 1x1 64->256"},
+                    {200704, 64, 256, "resnet50v2 stage2 _1_conv 1x1 256->64"},
+                    {50176, 512, 128, "resnet50v2 stage3 _3_conv 1x1 128->512"}};
   const int only_shape = argc > 1 ? atoi(argv[1]) : -1;
   const int only_cfg = argc > 2 ? atoi(argv[2]) : -1;
   int shape_idx = -1;
