@@ -35,9 +35,14 @@
 namespace dif {
 
 // A-operand loader: gathers BM output pixels x 32 k-values per step.
-template <int N, int RP>
+template <int N, int RP, bool PRE>
 struct ConvALoader {
   __amdgpu_buffer_rsrc_t rsrc;
+  const float* ps;   // pre-activation scale / shift per input channel (PRE only)
+  const float* pt;
+  int pre_act;
+  f32x4 cs, ct;      // this K-step's scale / shift for the thread's 4 channels
+  unsigned okmask;   // bit i: row i's chunk of this K-step is inside the image
   int32_t base[N];   // byte offset of (n - n_first, hi0, wi0, 0) relative to the tile's first image (may be < 0)
   int32_t hw0[N];    // hi0 in the high 16 bits, wi0 in the low 16 bits (biased by 0x4000 each)
   int H, W, Cin, KW, taps;
@@ -53,6 +58,10 @@ struct ConvALoader {
     KW = a.KW;
     taps = a.KH * a.KW;
     fast = (a.Cin % BK) == 0;
+    ps = a.pre_scale;
+    pt = a.pre_shift;
+    pre_act = a.pre_act;
+    okmask = 0;
     const int HoWo = a.Ho * a.Wo;
     fd_cin = a.fd_cin;
     fd_kw = a.fd_kw;
@@ -80,21 +89,24 @@ struct ConvALoader {
     }
   }
 
-  __device__ __forceinline__ void load(int kstep, f32x4 (&r)[N]) const {
-    int kh, kw, toff;
+  __device__ __forceinline__ void load(int kstep, f32x4 (&r)[N]) {
+    int kh, kw, toff, cch;
     bool tap_ok = true;
     if (fast) {
       int tap, ci0;
       fd_cin.divmod(kstep * BK, tap, ci0);
       fd_kw.divmod(tap, kh, kw);
       toff = ((kh * W + kw) * Cin + ci0) * 4;
+      cch = ci0 + (threadIdx.x & 7) * 4;
     } else {
       int tap, ci;
       fd_cin.divmod(kstep * BK + (threadIdx.x & 7) * 4, tap, ci);
       fd_kw.divmod(tap, kh, kw);
       tap_ok = tap < taps;
       toff = ((kh * W + kw) * Cin + ci) * 4 - (threadIdx.x & 7) * 16;
+      cch = tap_ok ? ci : 0;
     }
+    unsigned mask = 0;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       const int hi = (hw0[i] >> 16) - 0x4000 + kh;
@@ -102,6 +114,28 @@ struct ConvALoader {
       const bool ok = tap_ok && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
       const uint32_t off = ok ? (uint32_t)(base[i] + toff) : OOB;
       r[i] = buf_load4(rsrc, off);
+      mask |= ok ? (1u << i) : 0u;
+    }
+    if constexpr (PRE) {
+      okmask = mask;
+      cs = *reinterpret_cast<const f32x4*>(ps + cch);
+      ct = *reinterpret_cast<const f32x4*>(pt + cch);
+    }
+  }
+
+  // pre-activation of the gathered chunk, applied just before it is written to LDS
+  __device__ __forceinline__ void finish(f32x4 (&r)[N]) const {
+    if constexpr (PRE) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const bool ok = (okmask >> i) & 1u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v = fmaf(r[i][j], cs[j], ct[j]);
+          if (pre_act == ACT_RELU) v = fmaxf(v, 0.f);
+          r[i][j] = ok ? v : 0.f;
+        }
+      }
     }
   }
 };
@@ -198,7 +232,7 @@ __device__ __forceinline__ int xcd_remap(int b, int P) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }
 
-template <class T>
+template <class T, bool PRE>
 __global__ __launch_bounds__(T::NT, 2) void conv_igemm_kernel(const ConvArgs a) {
   constexpr int WM = T::WM, WN = T::WN;
   constexpr int SLAB = T::BM * T::BN;    // floats per partial-accumulator slab
@@ -224,7 +258,7 @@ __global__ __launch_bounds__(T::NT, 2) void conv_igemm_kernel(const ConvArgs a) 
 
     f32x16 acc[WM][WN];
     zero_acc<T>(acc);
-    ConvALoader<T::NA, T::RP> al(a, m0);
+    ConvALoader<T::NA, T::RP, PRE> al(a, m0);
     RowLoader<T::NB, T::RP> bl(a.w + (int64_t)n0 * a.Kpad, (int64_t)a.Cout - n0, a.Kpad);
     gemm_mainloop<T>(al, bl, kb, ke, smem, acc);
 
@@ -316,10 +350,19 @@ static int num_cus() {
 int conv_max_blocks() { return 4 * num_cus(); }
 size_t conv_slab_floats() { return 128 * 128; }
 
+template <class T, bool PRE>
+static int launch_conv_pre(const ConvArgs& a, hipStream_t st);
+
 template <class T>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
+  if (a.pre_scale) return launch_conv_pre<T, true>(a, st);
+  return launch_conv_pre<T, false>(a, st);
+}
+
+template <class T, bool PRE>
+static int launch_conv_pre(const ConvArgs& a, hipStream_t st) {
   static bool attr_set = false;
-  auto kern = conv_igemm_kernel<T>;
+  auto kern = conv_igemm_kernel<T, PRE>;
   if (!attr_set) {
     DIF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 T::LDS_BYTES));
@@ -380,6 +423,7 @@ int conv_run(const ConvArgs& a, int tile, hipStream_t st) {
   if (a.Cout % 4 != 0) return set_error("conv: Cout must be a multiple of 4 (got %d)", a.Cout);
   if (a.Kpad % BK != 0) return set_error("conv: Kpad must be a multiple of %d", BK);
   if (a.H >= 0x3f00 || a.W >= 0x3f00) return set_error("conv: spatial size too large");
+  if ((a.pre_scale == nullptr) != (a.pre_shift == nullptr)) return set_error("conv: pre_scale and pre_shift go together");
   if (!a.sk_slab || !a.sk_flag || a.sk_max_blocks < 1) return set_error("conv: stream-K workspace missing");
   {
     const int64_t howo = (int64_t)a.Ho * a.Wo;

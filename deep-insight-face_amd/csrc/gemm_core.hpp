@@ -58,7 +58,9 @@ __device__ __forceinline__ int frag_col(int lane) { return lane & 31; }
 
 // Accumulates K-steps [kbeg, kend) into acc.  Ends on a barrier (LDS is free afterwards).
 // Loader concept:
-//   struct L { __device__ void load(int kstep, f32x4 (&r)[N]); };
+//   struct L { __device__ void load(int kstep, f32x4 (&r)[N]);    // issue the loads of one K-step
+//              __device__ void finish(f32x4 (&r)[N]); };          // A side only: run just before the
+//                                                                 // LDS write (pre-activation transform)
 // Row i of the thread's share is tile row (tid>>3) + RP*i, chunk (tid&7) of the
 // K-step (floats 4*(tid&7) .. +3).
 template <class T, class ALoader, class BLoader>
@@ -80,6 +82,7 @@ __device__ __forceinline__ void gemm_mainloop(ALoader& al, BLoader& bl, int kbeg
   f32x4 ra[NA], rb[NB];
   al.load(kbeg, ra);
   bl.load(kbeg, rb);
+  al.finish(ra);
 #pragma unroll
   for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(lds + st_off + i * RP * LDS_STRIDE) = ra[i];
 #pragma unroll
@@ -123,6 +126,7 @@ __device__ __forceinline__ void gemm_mainloop(ALoader& al, BLoader& bl, int kbeg
     if (more) {
       float* wa = lds + (cur ^ 1) * BUF + st_off;
       float* wb = lds + (cur ^ 1) * BUF + OFFB + st_off;
+      al.finish(ra);
 #pragma unroll
       for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(wa + i * RP * LDS_STRIDE) = ra[i];
 #pragma unroll
@@ -170,6 +174,7 @@ struct RowLoader {
     ldb = (uint32_t)ld * 4u;
     off0 = (uint32_t)(tid >> 3) * ldb + (uint32_t)(tid & 7) * 16u;
   }
+  __device__ __forceinline__ void finish(f32x4 (&)[N]) const {}
   __device__ __forceinline__ void load(int kstep, f32x4 (&r)[N]) const {
     const uint32_t o = off0 + (uint32_t)kstep * (BK * 4);
 #pragma unroll

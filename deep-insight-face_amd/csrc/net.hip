@@ -129,11 +129,9 @@ int Net::build_resnet50v2() {
   // conv1_pad(3) + conv1_conv 7x7/2 (bias); preact network: no BN/ReLU here
   int t = conv("conv1_conv", input_tensor, 7, 7, 2, 3, 64, true, none, ACT_NONE, -1, -1, 1, true, none, ACT_NONE,
                nullptr);
-  // pool1_pad(1) + MaxPool 3x3/2; second output = relu(conv2_block1_preact_bn(.))
+  // pool1_pad(1) + MaxPool 3x3/2
   static const int stacks[4][3] = {{64, 3, 2}, {128, 4, 2}, {256, 6, 2}, {512, 3, 1}};
-  // BN parameter tables must be registered in model order: do it lazily per block below,
-  // but the preact BN of a block is consumed by the PREVIOUS op's epilogue, so create it first.
-  int x, pre;
+  int x, pre = -1;
   {
     const TensorDesc td = tensors[t];
     Op p;
@@ -146,14 +144,14 @@ int Net::build_resnet50v2() {
     p.zero_pad = 1;
     p.Cin = p.Cout = td.C;
     const int Ho = (td.H + 2 - 3) / 2 + 1, Wo = (td.W + 2 - 3) / 2 + 1;
-    p.bn2 = BN("conv2_block1_preact_bn", 64, EPS_RESNET);
-    p.act2 = ACT_RELU;
     p.y = T(Ho, Wo, td.C);
-    p.y2 = T(Ho, Wo, td.C);
     x = p.y;
-    pre = p.y2;
     ops.push_back(p);
   }
+  // Pre-activation blocks.  relu(preact_bn(x)) feeds only 1x1 convolutions (the block's
+  // _1_conv and, on block 1, its _0_conv shortcut), so it is never written to memory: those
+  // convolutions apply it to x while gathering their A operand.  Only the block output x
+  // itself (needed un-activated by the next identity shortcut) is stored.
   int cin = 64;
   for (int s = 0; s < 4; ++s) {
     const int f = stacks[s][0], nb = stacks[s][1], stride1 = stacks[s][2];
@@ -163,36 +161,33 @@ int Net::build_resnet50v2() {
       const std::string n(nm);
       const bool conv_shortcut = (b == 1);
       const int stride = (b == nb) ? stride1 : 1;
+      const BNRef pbn = BN(n + "_preact_bn", cin, EPS_RESNET);
       int sc = -1;
-      if (conv_shortcut)
-        sc = conv(n + "_0_conv", pre, 1, 1, stride, 0, 4 * f, true, none, ACT_NONE, -1, -1, 1, true, none,
-                  ACT_NONE, nullptr);
+      if (conv_shortcut) {
+        sc = conv(n + "_0_conv", x, 1, 1, stride, 0, 4 * f, true, none, ACT_NONE, -1, -1, 1, true, none, ACT_NONE,
+                  nullptr);
+        ops.back().pre_bn = pbn;
+        ops.back().pre_act = ACT_RELU;
+      }
       const BNRef bn1 = BN(n + "_1_bn", f, EPS_RESNET);
-      // parameter order inside a block follows the oracle's spec: _1_conv kernel precedes _1_bn
-      // (order is cosmetic: parameters are addressed by name)
-      int y1 = conv(n + "_1_conv", pre, 1, 1, 1, 0, f, false, bn1, ACT_RELU, -1, -1, 1, true, none, ACT_NONE,
-                    nullptr);
+      int y1 = conv(n + "_1_conv", x, 1, 1, 1, 0, f, false, bn1, ACT_RELU, -1, -1, 1, true, none, ACT_NONE, nullptr);
+      ops.back().pre_bn = pbn;
+      ops.back().pre_act = ACT_RELU;
       const BNRef bn2 = BN(n + "_2_bn", f, EPS_RESNET);
       int y2 = conv(n + "_2_conv", y1, 3, 3, stride, 1, f, false, bn2, ACT_RELU, -1, -1, 1, true, none, ACT_NONE,
                     nullptr);
-      // next pre-activation BN (or post_bn after the very last block)
-      std::string next;
-      int next_c = 4 * f;
       const bool last = (s == 3 && b == nb);
-      if (last)
-        next = "post_bn";
-      else if (b == nb)
-        snprintf(nm, sizeof(nm), "conv%d_block1_preact_bn", s + 3), next = nm;
-      else
-        snprintf(nm, sizeof(nm), "conv%d_block%d_preact_bn", s + 2, b + 1), next = nm;
-      const BNRef nbn = BN(next, next_c, EPS_RESNET);
-      int pre_next = -1;
       const int res = conv_shortcut ? sc : x;
       const int res_stride = conv_shortcut ? 1 : stride;   // MaxPooling2D(1, strides=stride) on the shortcut
-      int xn = conv(n + "_3_conv", y2, 1, 1, 1, 0, 4 * f, true, none, ACT_NONE, -1, res, res_stride, !last, nbn,
-                    ACT_RELU, &pre_next);
-      x = xn;
-      pre = pre_next;
+      if (last) {
+        // the network output relu(post_bn(.)) is a real tensor: second output of the last conv
+        const BNRef post = BN("post_bn", 4 * f, EPS_RESNET);
+        conv(n + "_3_conv", y2, 1, 1, 1, 0, 4 * f, true, none, ACT_NONE, -1, res, res_stride, false, post, ACT_RELU,
+             &pre);
+      } else {
+        x = conv(n + "_3_conv", y2, 1, 1, 1, 0, 4 * f, true, none, ACT_NONE, -1, res, res_stride, true, none,
+                 ACT_NONE, nullptr);
+      }
       cin = 4 * f;
     }
   }
@@ -437,6 +432,11 @@ int Net::finalize(int mb) {
       if (!scale.empty() && upload(this, scale, &op.d_scale)) return -1;
       if (!shift.empty() && upload(this, shift, &op.d_shift)) return -1;
     }
+    if (op.pre_bn.valid()) {
+      fold(this, op.pre_bn, -1, op.Cin, &scale, &shift);
+      if (upload(this, scale, &op.d_pre_scale)) return -1;
+      if (upload(this, shift, &op.d_pre_shift)) return -1;
+    }
     if (op.y2 >= 0) {
       fold(this, op.bn2, -1, op.Cout, &scale, &shift);
       if (!scale.empty() && upload(this, scale, &op.d_scale2)) return -1;
@@ -576,6 +576,9 @@ int Net::embed(const void* xin, int n, int layout, int dtype, float* out, hipStr
         a.scale2 = op.d_scale2;
         a.shift2 = op.d_shift2;
         a.alpha2 = op.d_alpha2;
+        a.pre_scale = op.d_pre_scale;
+        a.pre_shift = op.d_pre_shift;
+        a.pre_act = op.pre_act;
         a.N = n;
         a.H = xd.H;
         a.W = xd.W;

@@ -49,6 +49,8 @@ struct Op {
   // parameters
   int w = -1, bias = -1, alpha = -1, alpha2 = -1;
   BNRef bn, bn2;
+  BNRef pre_bn;               // pre-activation BN applied to the input while it is gathered
+  int pre_act = ACT_NONE;
   int act = ACT_NONE, act2 = ACT_NONE;
   // device side (filled by finalize)
   float* d_w = nullptr;
@@ -58,6 +60,8 @@ struct Op {
   float* d_scale2 = nullptr;
   float* d_shift2 = nullptr;
   float* d_alpha2 = nullptr;
+  float* d_pre_scale = nullptr;
+  float* d_pre_shift = nullptr;
   int Kpad = 0;
   double macs = 0;   // per image
 };

@@ -50,6 +50,11 @@ struct ConvArgs {
   const float* scale2;
   const float* shift2;
   const float* alpha2;
+  // optional pre-activation applied to the INPUT while it is gathered (per input channel):
+  // x' = pre_act(x * pre_scale[ci] + pre_shift[ci]); padded taps stay exactly zero
+  const float* pre_scale;
+  const float* pre_shift;
+  int pre_act;
   int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_t, pad_l;
   int Kpad;
   int M;                // N*Ho*Wo
