@@ -178,6 +178,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
   const int r0 = tid / CPR;
   const int c = n0 + c4 * 4;
   if (c < a.Cout) {
+    const bool plain_out = (a.y_H == a.Ho && a.y_W == a.Wo && a.y_oy == 0 && a.y_ox == 0);
     const f32x4 sc = load4_or(a.scale, c, 1.f), sh = load4_or(a.shift, c, 0.f), al = load4_or(a.alpha, c, 0.f);
     const f32x4 sc2 = load4_or(a.scale2, c, 1.f), sh2 = load4_or(a.shift2, c, 0.f), al2 = load4_or(a.alpha2, c, 0.f);
     const bool strided_res = a.res != nullptr && (a.res_stride != 1 || a.res_H != a.Ho || a.res_W != a.Wo);
@@ -216,7 +217,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
           v[j] = t;
           v2[j] = apply_act(fmaf(t, sc2[j], sh2[j]), a.act2, al2[j]);
         }
-        const int64_t o = (int64_t)row * a.Cout + c;
+        int64_t o;
+        if (plain_out) {
+          o = (int64_t)row * a.y_ld + a.y_coff + c;
+        } else {
+          int img, rr, ho, wo;
+          a.fd_howo.divmod(row, img, rr);
+          a.fd_wo.divmod(rr, ho, wo);
+          o = (((int64_t)img * a.y_H + ho + a.y_oy) * a.y_W + wo + a.y_ox) * a.y_ld + a.y_coff + c;
+        }
         if (a.y) *reinterpret_cast<f32x4*>(a.y + o) = v;
         if (a.y2) *reinterpret_cast<f32x4*>(a.y2 + o) = v2;
       }
@@ -421,6 +430,9 @@ int conv_run(const ConvArgs& a, int tile, hipStream_t st) {
   if (a.M <= 0) return 0;
   if (a.Cin % 4 != 0) return set_error("conv: Cin must be a multiple of 4 (got %d)", a.Cin);
   if (a.Cout % 4 != 0) return set_error("conv: Cout must be a multiple of 4 (got %d)", a.Cout);
+  if (a.y_ld % 4 != 0 || a.y_coff % 4 != 0) return set_error("conv: output view must be 16-byte aligned");
+  if (a.y_ld < a.y_coff + a.Cout || a.y_H < a.Ho + a.y_oy || a.y_W < a.Wo + a.y_ox)
+    return set_error("conv: output view does not fit its parent tensor");
   if (a.Kpad % BK != 0) return set_error("conv: Kpad must be a multiple of %d", BK);
   if (a.H >= 0x3f00 || a.W >= 0x3f00) return set_error("conv: spatial size too large");
   if ((a.pre_scale == nullptr) != (a.pre_shift == nullptr)) return set_error("conv: pre_scale and pre_shift go together");

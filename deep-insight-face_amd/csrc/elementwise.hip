@@ -54,10 +54,11 @@ int input_convert_run(const InputArgs& a, hipStream_t st) {
   return 0;
 }
 
-// ---------------------------------------------------------------- max pooling
+// ---------------------------------------------------------------- pooling (max / L2 / average)
 __global__ __launch_bounds__(256) void maxpool_kernel(const PoolArgs a) {
   const int C4 = a.C / 4;
   const int64_t total = (int64_t)a.N * a.Ho * a.Wo * C4;
+  const float inv_kk = 1.f / (float)(a.k * a.k);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int c4 = (int)(i % C4);
     int64_t p = i / C4;
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const PoolArgs a) {
     const int ho = (int)(p % a.Ho);
     const int64_t n = p / a.Ho;
     const float lo = -__builtin_inff();
-    f32x4 m = {lo, lo, lo, lo};
+    f32x4 m = (a.mode == POOL_MAX) ? f32x4{lo, lo, lo, lo} : f32x4{0.f, 0.f, 0.f, 0.f};
     bool padded = false;
     for (int kh = 0; kh < a.k; ++kh) {
       const int hi = ho * a.stride - a.pad_t + kh;
@@ -74,18 +75,35 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const PoolArgs a) {
         const int wi = wo * a.stride - a.pad_l + kw;
         if ((unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W) {
           const f32x4 v = *reinterpret_cast<const f32x4*>(a.x + ((n * a.H + hi) * a.W + wi) * a.C + c4 * 4);
-          m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (a.mode == POOL_MAX)
+              m[j] = fmaxf(m[j], v[j]);
+            else if (a.mode == POOL_L2)
+              m[j] = fmaf(v[j], v[j], m[j]);
+            else
+              m[j] += v[j];
+          }
         } else {
           padded = true;
         }
       }
     }
-    if (padded && a.zero_pad) {
-      m[0] = fmaxf(m[0], 0.f); m[1] = fmaxf(m[1], 0.f); m[2] = fmaxf(m[2], 0.f); m[3] = fmaxf(m[3], 0.f);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (a.mode == POOL_MAX) {
+        if (padded && a.zero_pad) m[j] = fmaxf(m[j], 0.f);
+      } else if (a.mode == POOL_L2) {
+        // x**2 -> AveragePooling2D -> * 9 -> sqrt   (networks/inceptionv3.py:160-163)
+        m[j] = sqrtf((m[j] * inv_kk) * (float)(a.k * a.k));
+      } else {
+        m[j] *= inv_kk;
+      }
     }
-    const int64_t o = ((n * a.Ho + ho) * a.Wo + wo) * a.C + c4 * 4;
+    const int64_t o = (((n * a.y_H + ho + a.y_oy) * a.y_W + wo + a.y_ox)) * a.y_ld + a.y_coff + c4 * 4;
     *reinterpret_cast<f32x4*>(a.y + o) = m;
     if (a.y2) {
+      const int64_t o2 = ((n * a.Ho + ho) * a.Wo + wo) * a.C + c4 * 4;
       const f32x4 s = a.scale2 ? *reinterpret_cast<const f32x4*>(a.scale2 + c4 * 4) : f32x4{1.f, 1.f, 1.f, 1.f};
       const f32x4 t = a.shift2 ? *reinterpret_cast<const f32x4*>(a.shift2 + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
       f32x4 q;
@@ -94,18 +112,50 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const PoolArgs a) {
         q[j] = fmaf(m[j], s[j], t[j]);
         if (a.act2 == ACT_RELU) q[j] = fmaxf(q[j], 0.f);
       }
-      *reinterpret_cast<f32x4*>(a.y2 + o) = q;
+      *reinterpret_cast<f32x4*>(a.y2 + o2) = q;
     }
   }
 }
 
 int maxpool_run(const PoolArgs& a, hipStream_t st) {
-  if (a.C % 4 != 0) return set_error("maxpool: C must be a multiple of 4 (got %d)", a.C);
+  if (a.C % 4 != 0) return set_error("pool: C must be a multiple of 4 (got %d)", a.C);
+  if (a.y_ld % 4 != 0 || a.y_coff % 4 != 0) return set_error("pool: output view must be 16-byte aligned");
   const int64_t total = (int64_t)a.N * a.Ho * a.Wo * (a.C / 4);
   if (total == 0) return 0;
   int64_t blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  DIF_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- local response normalisation
+// tf.nn.lrn(x, alpha=1e-4, beta=0.75) (networks/inceptionv3.py:95): depth_radius 5, bias 1.
+__global__ __launch_bounds__(256) void lrn_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                  int64_t npix, int C, int radius, float bias, float alpha,
+                                                  float beta) {
+  const int64_t total = npix * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const int64_t base = i - c;
+    const int lo = c - radius < 0 ? 0 : c - radius;
+    const int hi = c + radius >= C ? C - 1 : c + radius;
+    float s = 0.f;
+    for (int j = lo; j <= hi; ++j) {
+      const float v = x[base + j];
+      s = fmaf(v, v, s);
+    }
+    y[i] = x[i] / powf(bias + alpha * s, beta);
+  }
+}
+
+int lrn_run(const float* x, float* y, int64_t npix, int C, int radius, float bias, float alpha, float beta,
+            hipStream_t st) {
+  const int64_t total = npix * C;
+  if (total == 0) return 0;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(lrn_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, y, npix, C, radius, bias, alpha, beta);
   DIF_HIP(hipGetLastError());
   return 0;
 }

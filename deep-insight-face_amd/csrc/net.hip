@@ -67,6 +67,50 @@ int Net::T(int H, int W, int C) {
   return (int)tensors.size() - 1;
 }
 
+int Net::V(int parent, int H, int W, int C, int coff, int oy, int ox) {
+  TensorDesc t;
+  t.H = H;
+  t.W = W;
+  t.C = C;
+  t.parent = parent;
+  t.coff = coff;
+  t.oy = oy;
+  t.ox = ox;
+  tensors.push_back(t);
+  return (int)tensors.size() - 1;
+}
+
+void Net::into(int parent, int coff, int oy, int ox) {
+  pend_parent = parent;
+  pend_coff = coff;
+  pend_oy = oy;
+  pend_ox = ox;
+}
+
+int Net::out_tensor(int H, int W, int C) {
+  if (pend_parent < 0) return T(H, W, C);
+  const int v = V(pend_parent, H, W, C, pend_coff, pend_oy, pend_ox);
+  pend_parent = -1;
+  return v;
+}
+
+int Net::pool(const std::string& name, int x, int k, int stride, int pad, int mode, int zero_pad) {
+  const TensorDesc td = tensors[x];
+  Op p;
+  p.kind = OP_MAXPOOL;
+  p.name = name;
+  p.x = x;
+  p.KH = p.KW = k;
+  p.stride = stride;
+  p.pad_t = p.pad_l = pad;
+  p.zero_pad = zero_pad;
+  p.pool_mode = mode;
+  p.Cin = p.Cout = td.C;
+  p.y = out_tensor((td.H + 2 * pad - k) / stride + 1, (td.W + 2 * pad - k) / stride + 1, td.C);
+  ops.push_back(p);
+  return p.y;
+}
+
 // Adds a convolution op.  `pad` is symmetric explicit zero padding (VALID on the padded
 // map, like Keras ZeroPadding2D + Conv2D); same_pad_even = TensorFlow 'SAME' for an even
 // kernel at stride 1 (pad 0 before, k-1 after).  Returns the y tensor (or -1 if !want_y).
@@ -106,7 +150,7 @@ int Net::conv(const std::string& name, int x, int KH, int KW, int stride, int pa
   op.bn2 = bn2;
   op.act2 = act2;
   op.macs = (double)Ho * Wo * KH * KW * op.Cin_true * Cout;
-  op.y = want_y ? T(Ho, Wo, Cout) : -1;
+  op.y = want_y ? out_tensor(Ho, Wo, Cout) : -1;
   if (y2_out) {
     op.y2 = T(Ho, Wo, Cout);
     *y2_out = op.y2;
@@ -340,6 +384,162 @@ int Net::build_iresnet(const int* layers) {
   return 0;
 }
 
+// ----------------------------------------------------------------------------- NN4.small2 (OpenFace)
+// deep_insight_face/networks/inceptionv3.py:93-309 (InceptionNetwork._load_model) and :312-335
+// (conv2d_bn).  Every Conv2D has a bias and is followed by BatchNormalization(epsilon=1e-5) and
+// ReLU; the inception branches are concatenated on the channel axis, which here means each
+// branch's last layer writes straight into its channel slice of the block's output tensor
+// (and, where the reference zero-pads a branch AFTER its last layer, into the interior of a
+// zero-filled map).
+int Net::build_nn4() {
+  const BNRef none;
+  if (in_h != 96 || in_w != 96)
+    return set_error("Invalid Input shape, Shape should be of dimension (96, 96, 3)");   // inceptionv3.py:66
+  const float eps = 1e-5f;
+  input_tensor = T(in_h, in_w, 4);
+  {
+    Op in;
+    in.kind = OP_INPUT;
+    in.name = "input";
+    in.y = input_tensor;
+    ops.push_back(in);
+  }
+  auto cbr = [&](const std::string& cname, const std::string& bname, int x, int k, int stride, int pad, int cout) {
+    const BNRef bn = BN(bname, cout, eps);
+    return conv(cname, x, k, k, stride, pad, cout, true, bn, ACT_RELU, -1, -1, 1, true, none, ACT_NONE, nullptr);
+  };
+  auto lrn = [&](const std::string& name, int x) {
+    const TensorDesc td = tensors[x];
+    Op l;
+    l.kind = OP_LRN;
+    l.name = name;
+    l.x = x;
+    l.Cin = l.Cout = td.C;
+    l.y = T(td.H, td.W, td.C);
+    ops.push_back(l);
+    return l.y;
+  };
+  auto zero = [&](int t) {
+    Op z;
+    z.kind = OP_ZERO;
+    z.name = "zero_fill";
+    z.y = t;
+    ops.push_back(z);
+  };
+  // two-conv branch of conv2d_bn(): 1x1 -> pad -> kxk (stride s), written into a concat slice
+  auto branch2 = [&](const std::string& layer, int x, int c1, int c2, int k, int stride, int pad, int cat, int coff) {
+    const int t = cbr(layer + "_conv1", layer + "_bn1", x, 1, 1, 0, c1);
+    into(cat, coff);
+    return cbr(layer + "_conv2", layer + "_bn2", t, k, stride, pad, c2);
+  };
+
+  // stem: inceptionv3.py:96-112
+  int x = cbr("conv1", "bn1", input_tensor, 7, 2, 3, 64);                 // 48x48x64
+  x = pool("pool1", x, 3, 2, 1, POOL_MAX, 1);                             // 24x24x64
+  x = lrn("lrn_1", x);
+  x = cbr("conv2", "bn2", x, 1, 1, 0, 64);
+  x = cbr("conv3", "bn3", x, 3, 1, 1, 192);
+  x = lrn("lrn_2", x);
+  x = pool("pool2", x, 3, 2, 1, POOL_MAX, 1);                             // 12x12x192
+
+  // inception 3a: :114-141   concat [3x3 128, 5x5 32, pool 32, 1x1 64] = 256
+  {
+    const int cat = T(12, 12, 256);
+    zero(cat);
+    branch2("inception_3a_3x3", x, 96, 128, 3, 1, 1, cat, 0);
+    branch2("inception_3a_5x5", x, 16, 32, 5, 1, 2, cat, 128);
+    const int p = pool("inception_3a_pool", x, 3, 2, 0, POOL_MAX, 0);     // 5x5x192
+    into(cat, 160, 3, 3);                                                 // ZeroPadding2D(((3,4),(3,4)))
+    cbr("inception_3a_pool_conv", "inception_3a_pool_bn", p, 1, 1, 0, 32);
+    into(cat, 192);
+    cbr("inception_3a_1x1_conv", "inception_3a_1x1_bn", x, 1, 1, 0, 64);
+    x = cat;
+  }
+  // inception 3b: :143-174   concat [128, 64, pool 64, 64] = 320
+  {
+    const int cat = T(12, 12, 320);
+    zero(cat);
+    branch2("inception_3b_3x3", x, 96, 128, 3, 1, 1, cat, 0);
+    branch2("inception_3b_5x5", x, 32, 64, 5, 1, 2, cat, 128);
+    const int p = pool("inception_3b_pool", x, 3, 3, 0, POOL_L2, 0);      // 4x4x256
+    into(cat, 192, 4, 4);                                                 // ZeroPadding2D((4,4))
+    cbr("inception_3b_pool_conv", "inception_3b_pool_bn", p, 1, 1, 0, 64);
+    into(cat, 256);
+    cbr("inception_3b_1x1_conv", "inception_3b_1x1_bn", x, 1, 1, 0, 64);
+    x = cat;
+  }
+  // inception 3c: :176-199   concat [256, 64, pool 320] = 640 at 6x6
+  {
+    const int cat = T(6, 6, 640);
+    zero(cat);
+    branch2("inception_3c_3x3", x, 128, 256, 3, 2, 1, cat, 0);
+    branch2("inception_3c_5x5", x, 32, 64, 5, 2, 2, cat, 256);
+    into(cat, 320, 0, 0);                                                 // 5x5 map, ZeroPadding2D(((0,1),(0,1)))
+    pool("inception_3c_pool", x, 3, 2, 0, POOL_MAX, 0);
+    x = cat;
+  }
+  // inception 4a: :201-232   concat [192, 64, pool 128, 256] = 640
+  {
+    const int cat = T(6, 6, 640);
+    zero(cat);
+    branch2("inception_4a_3x3", x, 96, 192, 3, 1, 1, cat, 0);
+    branch2("inception_4a_5x5", x, 32, 64, 5, 1, 2, cat, 192);
+    const int p = pool("inception_4a_pool", x, 3, 3, 0, POOL_L2, 0);      // 2x2x640
+    into(cat, 256, 2, 2);                                                 // padding=(2,2)
+    cbr("inception_4a_pool_conv", "inception_4a_pool_bn", p, 1, 1, 0, 128);
+    into(cat, 384);
+    cbr("inception_4a_1x1_conv", "inception_4a_1x1_bn", x, 1, 1, 0, 256);
+    x = cat;
+  }
+  // inception 4e: :234-255   concat [256, 128, pool 640] = 1024 at 3x3
+  {
+    const int cat = T(3, 3, 1024);
+    zero(cat);
+    branch2("inception_4e_3x3", x, 160, 256, 3, 2, 1, cat, 0);
+    branch2("inception_4e_5x5", x, 64, 128, 5, 2, 2, cat, 256);
+    into(cat, 384, 0, 0);                                                 // 2x2 map, ZeroPadding2D(((0,1),(0,1)))
+    pool("inception_4e_pool", x, 3, 2, 0, POOL_MAX, 0);
+    x = cat;
+  }
+  // inception 5a: :257-283   concat [384, pool 96, 256] = 736
+  {
+    const int cat = T(3, 3, 736);
+    zero(cat);
+    branch2("inception_5a_3x3", x, 96, 384, 3, 1, 1, cat, 0);
+    const int p = pool("inception_5a_pool", x, 3, 3, 0, POOL_L2, 0);      // 1x1x1024
+    into(cat, 384, 1, 1);                                                 // padding=(1,1)
+    cbr("inception_5a_pool_conv", "inception_5a_pool_bn", p, 1, 1, 0, 96);
+    into(cat, 480);
+    cbr("inception_5a_1x1_conv", "inception_5a_1x1_bn", x, 1, 1, 0, 256);
+    x = cat;
+  }
+  // inception 5b: :285-306   concat [384, pool 96, 256] = 736
+  {
+    const int cat = T(3, 3, 736);
+    zero(cat);
+    branch2("inception_5b_3x3", x, 96, 384, 3, 1, 1, cat, 0);
+    const int p = pool("inception_5b_pool", x, 3, 2, 0, POOL_MAX, 0);     // 1x1x736
+    into(cat, 384, 1, 1);                                                 // ZeroPadding2D((1,1))
+    cbr("inception_5b_pool_conv", "inception_5b_pool_bn", p, 1, 1, 0, 96);
+    into(cat, 480);
+    cbr("inception_5b_1x1_conv", "inception_5b_1x1_bn", x, 1, 1, 0, 256);
+    x = cat;
+  }
+  // :308-311  AveragePooling2D(3, strides 1) -> Flatten -> Dense(emd) -> l2_normalize
+  x = pool("avg_pool", x, 3, 1, 0, POOL_AVG, 0);                          // 1x1x736
+  int d = conv("dense_layer", x, 1, 1, 1, 0, emd, true, none, ACT_NONE, -1, -1, 1, true, none, ACT_NONE, nullptr);
+  params[ops.back().w].shape = {736, emd};
+  Op l;
+  l.kind = OP_L2NORM;
+  l.name = "norm_layer";
+  l.x = d;
+  l.Cin = l.Cout = emd;
+  l.y = T(1, 1, emd);
+  ops.push_back(l);
+  output_tensor = l.y;
+  return 0;
+}
+
 int Net::build() {
   if (emd <= 0) return set_error("emd_size must be positive");
   if (in_h < 32 || in_w < 32) return set_error("input must be at least 32x32");
@@ -348,13 +548,14 @@ int Net::build() {
     static const int l[4] = {3, 4, 14, 3};
     return build_iresnet(l);
   }
+  if (arch == "nn4") return build_nn4();
   if (arch == "iresnet100") {
     static const int l[4] = {3, 13, 30, 3};
     return build_iresnet(l);
   }
   // the reference asserts net in ('mobilenet','resnet','vgg16') (triplet.py:77); only the
   // ResNet path is on the hot path named by north_star
-  return set_error("Invalid bottleneck network '%s' (supported: resnet, iresnet50, iresnet100)", arch.c_str());
+  return set_error("Invalid bottleneck network '%s' (supported: resnet, iresnet50, iresnet100, nn4)", arch.c_str());
 }
 
 double Net::flops_per_image() const {
@@ -447,11 +648,13 @@ int Net::finalize(int mb) {
 
   // ---- activation buffers: liveness over the op list, first-fit reuse
   for (TensorDesc& t : tensors) t.first_def = t.last_use = t.buf = -1;
+  // views share their parent's storage: liveness and buffers are tracked on the root tensor
+  auto R = [&](int t) { return t < 0 ? t : root_of(t); };
   for (int i = 0; i < (int)ops.size(); ++i) {
     const Op& op = ops[i];
-    for (int t : {op.y, op.y2})
+    for (int t : {R(op.y), R(op.y2)})
       if (t >= 0 && tensors[t].first_def < 0) tensors[t].first_def = i;
-    for (int t : {op.x, op.res, op.y, op.y2})
+    for (int t : {R(op.x), R(op.res), R(op.y), R(op.y2)})
       if (t >= 0) tensors[t].last_use = std::max(tensors[t].last_use, i);
   }
   tensors[output_tensor].last_use = (int)ops.size();   // written straight into the caller's buffer
@@ -459,7 +662,7 @@ int Net::finalize(int mb) {
   std::vector<int> free_list;
   for (int i = 0; i < (int)ops.size(); ++i) {
     const Op& op = ops[i];
-    for (int t : {op.y, op.y2}) {
+    for (int t : {R(op.y), R(op.y2)}) {
       if (t < 0 || t == output_tensor || tensors[t].buf >= 0) continue;
       const int64_t need = tensors[t].elems();
       int best = -1;
@@ -475,7 +678,7 @@ int Net::finalize(int mb) {
         tensors[t].buf = (int)buf_elems.size() - 1;
       }
     }
-    for (int t : {op.x, op.res, op.y, op.y2})
+    for (int t : {R(op.x), R(op.res), R(op.y), R(op.y2)})
       if (t >= 0 && t != output_tensor && tensors[t].last_use == i && tensors[t].buf >= 0) {
         if (std::find(free_list.begin(), free_list.end(), tensors[t].buf) == free_list.end())
           free_list.push_back(tensors[t].buf);
@@ -512,6 +715,8 @@ const char* Net::kernel_name(const Op& op, int n) const {
     case OP_MAXPOOL: return "maxpool_kernel";
     case OP_DWFULL: return "dwfull_kernel";
     case OP_L2NORM: return "l2norm_kernel";
+    case OP_LRN: return "lrn_kernel";
+    case OP_ZERO: return "memset";
     case OP_CONV: {
       const TensorDesc& yd = tensors[op.y >= 0 ? op.y : op.y2];
       static const char* names[4] = {"conv_igemm_kernel<128x128>", "conv_igemm_kernel<128x64>",
@@ -532,7 +737,7 @@ int Net::embed(const void* xin, int n, int layout, int dtype, float* out, hipStr
   auto ptr = [&](int t) -> float* {
     if (t < 0) return nullptr;
     if (t == output_tensor) return out;
-    return bufs[tensors[t].buf];
+    return bufs[tensors[root_of(t)].buf];
   };
   std::vector<hipEvent_t> ev;
   if (op_ms) {
@@ -604,6 +809,24 @@ int Net::embed(const void* xin, int n, int layout, int dtype, float* out, hipStr
           a.res_W = yd.W;
           a.res_stride = 1;
         }
+        {
+          const TensorDesc& vd = tensors[op.y >= 0 ? op.y : op.y2];
+          if (vd.parent >= 0) {
+            const TensorDesc& pd = tensors[vd.parent];
+            a.y_ld = pd.C;
+            a.y_coff = vd.coff;
+            a.y_H = pd.H;
+            a.y_W = pd.W;
+            a.y_oy = vd.oy;
+            a.y_ox = vd.ox;
+          } else {
+            a.y_ld = op.Cout;
+            a.y_coff = 0;
+            a.y_H = yd.H;
+            a.y_W = yd.W;
+            a.y_oy = a.y_ox = 0;
+          }
+        }
         a.sk_slab = sk_slab;
         a.sk_flag = sk_flag;
         a.sk_max_blocks = sk_max_blocks;
@@ -634,12 +857,39 @@ int Net::embed(const void* xin, int n, int layout, int dtype, float* out, hipStr
         a.pad_l = op.pad_l;
         a.zero_pad = op.zero_pad;
         a.act2 = op.act2;
+        a.mode = op.pool_mode;
+        if (yd.parent >= 0) {
+          const TensorDesc& pd = tensors[yd.parent];
+          a.y_ld = pd.C;
+          a.y_coff = yd.coff;
+          a.y_H = pd.H;
+          a.y_W = pd.W;
+          a.y_oy = yd.oy;
+          a.y_ox = yd.ox;
+        } else {
+          a.y_ld = yd.C;
+          a.y_coff = 0;
+          a.y_H = yd.H;
+          a.y_W = yd.W;
+          a.y_oy = a.y_ox = 0;
+        }
         if (maxpool_run(a, st)) return -1;
         break;
       }
       case OP_DWFULL: {
         const TensorDesc& xd = tensors[op.x];
         if (dwfull_run(ptr(op.x), op.d_w, op.d_scale, op.d_shift, ptr(op.y), n, xd.H * xd.W, xd.C, st)) return -1;
+        break;
+      }
+      case OP_LRN: {
+        const TensorDesc& xd = tensors[op.x];
+        // tf.nn.lrn defaults: depth_radius 5, bias 1; alpha / beta from inceptionv3.py:95
+        if (lrn_run(ptr(op.x), ptr(op.y), (int64_t)n * xd.H * xd.W, xd.C, 5, 1.f, 1e-4f, 0.75f, st)) return -1;
+        break;
+      }
+      case OP_ZERO: {
+        const TensorDesc& yd = tensors[op.y];
+        DIF_HIP(hipMemsetAsync(ptr(op.y), 0, (size_t)n * yd.elems() * sizeof(float), st));
         break;
       }
       case OP_L2NORM:

@@ -29,12 +29,14 @@ struct BNRef {
 
 struct TensorDesc {
   int H = 0, W = 0, C = 0;
+  // view into a wider / larger parent tensor (inception concat, ZeroPadding2D after a layer)
+  int parent = -1, coff = 0, oy = 0, ox = 0;
   int buf = -1;
   int first_def = -1, last_use = -1;
   int64_t elems() const { return (int64_t)H * W * C; }
 };
 
-enum OpKind { OP_INPUT, OP_CONV, OP_MAXPOOL, OP_DWFULL, OP_L2NORM };
+enum OpKind { OP_INPUT, OP_CONV, OP_MAXPOOL, OP_DWFULL, OP_L2NORM, OP_LRN, OP_ZERO };
 
 struct Op {
   OpKind kind = OP_CONV;
@@ -45,6 +47,7 @@ struct Op {
   int Cin = 0, Cin_true = 0, Cout = 0;
   int res_stride = 1;
   int zero_pad = 0;
+  int pool_mode = POOL_MAX;
   bool chw_flatten = false;   // dense after an NCHW-order flatten: permute kernel rows at pack time
   // parameters
   int w = -1, bias = -1, alpha = -1, alpha2 = -1;
@@ -101,11 +104,18 @@ struct Net {
   int P(const std::string& name, std::vector<int64_t> shape);
   BNRef BN(const std::string& prefix, int C, float eps);
   int T(int H, int W, int C);
+  int V(int parent, int H, int W, int C, int coff, int oy, int ox);   // view tensor
+  void into(int parent, int coff, int oy = 0, int ox = 0);           // the next conv/pool writes into this view
+  int out_tensor(int H, int W, int C);
+  int pool(const std::string& name, int x, int k, int stride, int pad, int mode, int zero_pad);
+  int pend_parent = -1, pend_coff = 0, pend_oy = 0, pend_ox = 0;
+  int root_of(int t) const { return tensors[t].parent >= 0 ? tensors[t].parent : t; }
   int conv(const std::string& name, int x, int KH, int KW, int stride, int pad, int Cout, bool bias,
            const BNRef& bn, int act, int alpha, int res, int res_stride, bool want_y, const BNRef& bn2, int act2,
            int* y2_out, const std::string& wsuffix = "/kernel", bool same_pad_even = false);
   int build_resnet50v2();
   int build_iresnet(const int* layers);
+  int build_nn4();
 };
 
 }  // namespace dif

@@ -60,6 +60,11 @@ struct ConvArgs {
   int M;                // N*Ho*Wo
   int act, act2;
   int res_H, res_W, res_stride;
+  // Output view: y (and y2) may be a channel slice of a wider tensor (inception concat) and/or
+  // sit inside a larger zero-initialised map (ZeroPadding2D after the layer):
+  //   y[((n*y_H + ho + y_oy)*y_W + wo + y_ox)*y_ld + y_coff + c]
+  // Plain output: y_ld = Cout, y_coff = 0, y_H = Ho, y_W = Wo, y_oy = y_ox = 0.
+  int y_ld, y_coff, y_H, y_W, y_oy, y_ox;
   // stream-K workspace (owned by the caller): one partial-accumulator slab and one flag per
   // persistent block; sk_epoch is unique per launch so flags never need clearing
   float* sk_slab;
@@ -76,17 +81,23 @@ size_t conv_slab_floats();    // floats per slab
 int conv_tile_choice(int64_t M, int Cout, int Kpad);
 int conv_run(const ConvArgs& a, int tile, hipStream_t st);
 
+enum { POOL_MAX = 0, POOL_L2 = 1, POOL_AVG = 2 };
 struct PoolArgs {
   const float* x;   // [N,H,W,C]
-  float* y;         // [N,Ho,Wo,C]
-  float* y2;        // optional relu(y*scale2 + shift2)
+  float* y;         // [N,Ho,Wo,C] or a view (see ConvArgs)
+  float* y2;        // optional relu(y*scale2 + shift2), plain layout
   const float* scale2;
   const float* shift2;
   int N, H, W, C, Ho, Wo, k, stride, pad_t, pad_l;
   int zero_pad;     // 1: padded taps contribute 0 (explicit ZeroPadding2D before a VALID pool)
   int act2;
+  int mode;         // POOL_MAX | POOL_L2 (sqrt(mean(x^2) * k*k), networks/inceptionv3.py:160-163) | POOL_AVG
+  int y_ld, y_coff, y_H, y_W, y_oy, y_ox;
 };
 int maxpool_run(const PoolArgs& a, hipStream_t st);
+// tf.nn.lrn over the channel axis: y = x / (bias + alpha * sum_{|j-c|<=radius} x_j^2)^beta
+int lrn_run(const float* x, float* y, int64_t npix, int C, int radius, float bias, float alpha, float beta,
+            hipStream_t st);
 
 // input conversion to the internal NHWC4 float layout
 struct InputArgs {

@@ -184,7 +184,9 @@ class bottleneck_network:
     but are not part of the accelerated path."""
 
     def __init__(self, net: str = "resnet", emd_size: int = 128, input_shape: typing.Tuple = (96, 96, 3), **kwargs):
-        assert net in ('mobilenet', 'resnet', 'vgg16', 'iresnet50', 'iresnet100'), "Invalid bottleneck network"
+        # 'inception' is handled by the reference's picker (triplet.py:94-99) although its assert omits it
+        assert net in ('mobilenet', 'resnet', 'vgg16', 'inception', 'iresnet50', 'iresnet100'), \
+            "Invalid bottleneck network"
         if net in ('mobilenet', 'vgg16'):
             raise NotImplementedError("bottleneck '%s' is outside the MI355X hot path (resnet, iresnet50, iresnet100)"
                                       % net)
@@ -198,7 +200,8 @@ class bottleneck_network:
         return getattr(self, 'build_models_' + default_model_ver)(dropout=dropout)
 
     def _build(self, head):
-        return DifEmbedder(self.net, head, self.emd_size, self.input_shape,
+        arch = 'nn4' if self.net == 'inception' else self.net
+        return DifEmbedder(arch, head, self.emd_size, self.input_shape,
                            max_batch=self.kwargs.get('max_batch', 256))
 
     def build_models_v1(self, dropout=0.3):

@@ -309,6 +309,8 @@ def model_spec(arch, emd=512, input_hw=112, head='v2'):
         return spec
     if arch in IRESNET_LAYERS:
         return iresnet_spec(arch, emd=emd, final_hw=input_hw // 16)
+    if arch == 'nn4':
+        return nn4_spec(emd)
     raise ValueError(arch)
 
 
@@ -323,8 +325,146 @@ def embed(x, p, arch, emd=512, head='v2'):
         if head == 'v3':
             return f
         raise ValueError(head)
+    if arch == 'nn4':
+        return nn4_small2(x, p)
     return iresnet(x, p, arch)
 
 
 def cast_params(p, dtype):
     return {k: np.asarray(v, dtype=dtype) for k, v in p.items()}
+
+
+# --------------------------------------------------------------------------- NN4.small2 (OpenFace)
+# deep_insight_face/networks/inceptionv3.py:93-309 -- the one CNN fully defined inside the
+# reference repository.  TensorFlow is not installed, so the Keras / tf.nn primitives it calls
+# are restated from their public definitions: Conv2D (bias, VALID on an explicitly padded map),
+# BatchNormalization(epsilon=1e-5) at inference, tf.nn.lrn(depth_radius=5, bias=1, alpha, beta),
+# MaxPooling2D / AveragePooling2D (VALID).  Still "parity unpinned": no TF run pins these.
+NN4_EPS = 1e-5
+
+
+def lrn(x, depth_radius=5, bias=1.0, alpha=1e-4, beta=0.75):
+    """tf.nn.lrn: x / (bias + alpha * sum_{|j-c|<=r} x_j^2) ** beta over the channel axis
+    (inceptionv3.py:95: LRN2D = tf.nn.lrn(x, alpha=1e-4, beta=0.75))."""
+    sq = x * x
+    c = x.shape[-1]
+    pad = np.pad(sq, [(0, 0)] * (x.ndim - 1) + [(depth_radius, depth_radius)])
+    s = np.zeros_like(x)
+    for j in range(2 * depth_radius + 1):
+        s = s + pad[..., j:j + c]
+    return x / np.power(np.asarray(bias, x.dtype) + np.asarray(alpha, x.dtype) * s, np.asarray(beta, x.dtype))
+
+
+def avgpool(x, k, stride):
+    n, h, w, c = x.shape
+    ho, wo = (h - k) // stride + 1, (w - k) // stride + 1
+    s = x.strides
+    win = np.lib.stride_tricks.as_strided(x, shape=(n, ho, wo, k, k, c),
+                                          strides=(s[0], s[1] * stride, s[2] * stride, s[1], s[2], s[3]),
+                                          writeable=False)
+    return win.mean(axis=(3, 4), dtype=x.dtype)
+
+
+def _nn4_cbr(x, p, conv, bn, stride=1, pad=0):
+    y = conv2d(x, p[conv + '/kernel'], p[conv + '/bias'], stride=stride, pad=(pad, pad, pad, pad))
+    return relu(batchnorm(y, p, bn, NN4_EPS))
+
+
+def _nn4_branch(x, p, layer, stride, pad):
+    """conv2d_bn with two convolutions (inceptionv3.py:312-335)."""
+    y = _nn4_cbr(x, p, layer + '_conv1', layer + '_bn1')
+    return _nn4_cbr(y, p, layer + '_conv2', layer + '_bn2', stride=stride, pad=pad)
+
+
+def _zpad(x, t, b, l, r):
+    return np.pad(x, ((0, 0), (t, b), (l, r), (0, 0)))
+
+
+def _l2pool(x):
+    """x**2 -> AveragePooling2D(3, strides 3) -> * 9 -> sqrt (inceptionv3.py:160-163)."""
+    return np.sqrt(avgpool(x * x, 3, 3) * np.asarray(9, x.dtype))
+
+
+def nn4_small2(x, p):
+    """[N,96,96,3] -> unit-norm [N,emd].  inceptionv3.py:93-309."""
+    y = _nn4_cbr(x, p, 'conv1', 'bn1', stride=2, pad=3)
+    y = maxpool(y, 3, 2, pad=(1, 1, 1, 1))
+    y = lrn(y)
+    y = _nn4_cbr(y, p, 'conv2', 'bn2')
+    y = _nn4_cbr(y, p, 'conv3', 'bn3', pad=1)
+    y = lrn(y)
+    y = maxpool(y, 3, 2, pad=(1, 1, 1, 1))
+    # 3a
+    b3 = _nn4_branch(y, p, 'inception_3a_3x3', 1, 1)
+    b5 = _nn4_branch(y, p, 'inception_3a_5x5', 1, 2)
+    bp = _zpad(_nn4_cbr(maxpool(y, 3, 2), p, 'inception_3a_pool_conv', 'inception_3a_pool_bn'), 3, 4, 3, 4)
+    b1 = _nn4_cbr(y, p, 'inception_3a_1x1_conv', 'inception_3a_1x1_bn')
+    y = np.concatenate([b3, b5, bp, b1], axis=3)
+    # 3b
+    b3 = _nn4_branch(y, p, 'inception_3b_3x3', 1, 1)
+    b5 = _nn4_branch(y, p, 'inception_3b_5x5', 1, 2)
+    bp = _zpad(_nn4_cbr(_l2pool(y), p, 'inception_3b_pool_conv', 'inception_3b_pool_bn'), 4, 4, 4, 4)
+    b1 = _nn4_cbr(y, p, 'inception_3b_1x1_conv', 'inception_3b_1x1_bn')
+    y = np.concatenate([b3, b5, bp, b1], axis=3)
+    # 3c
+    b3 = _nn4_branch(y, p, 'inception_3c_3x3', 2, 1)
+    b5 = _nn4_branch(y, p, 'inception_3c_5x5', 2, 2)
+    bp = _zpad(maxpool(y, 3, 2), 0, 1, 0, 1)
+    y = np.concatenate([b3, b5, bp], axis=3)
+    # 4a
+    b3 = _nn4_branch(y, p, 'inception_4a_3x3', 1, 1)
+    b5 = _nn4_branch(y, p, 'inception_4a_5x5', 1, 2)
+    bp = _zpad(_nn4_cbr(_l2pool(y), p, 'inception_4a_pool_conv', 'inception_4a_pool_bn'), 2, 2, 2, 2)
+    b1 = _nn4_cbr(y, p, 'inception_4a_1x1_conv', 'inception_4a_1x1_bn')
+    y = np.concatenate([b3, b5, bp, b1], axis=3)
+    # 4e
+    b3 = _nn4_branch(y, p, 'inception_4e_3x3', 2, 1)
+    b5 = _nn4_branch(y, p, 'inception_4e_5x5', 2, 2)
+    bp = _zpad(maxpool(y, 3, 2), 0, 1, 0, 1)
+    y = np.concatenate([b3, b5, bp], axis=3)
+    # 5a
+    b3 = _nn4_branch(y, p, 'inception_5a_3x3', 1, 1)
+    bp = _zpad(_nn4_cbr(_l2pool(y), p, 'inception_5a_pool_conv', 'inception_5a_pool_bn'), 1, 1, 1, 1)
+    b1 = _nn4_cbr(y, p, 'inception_5a_1x1_conv', 'inception_5a_1x1_bn')
+    y = np.concatenate([b3, bp, b1], axis=3)
+    # 5b
+    b3 = _nn4_branch(y, p, 'inception_5b_3x3', 1, 1)
+    bp = _zpad(_nn4_cbr(maxpool(y, 3, 2), p, 'inception_5b_pool_conv', 'inception_5b_pool_bn'), 1, 1, 1, 1)
+    b1 = _nn4_cbr(y, p, 'inception_5b_1x1_conv', 'inception_5b_1x1_bn')
+    y = np.concatenate([b3, bp, b1], axis=3)
+    y = avgpool(y, 3, 1).reshape(y.shape[0], -1)
+    y = y @ p['dense_layer/kernel'] + p['dense_layer/bias']
+    return l2_normalize(y)
+
+
+# conv name -> (cout, cin, kh, kw), the reference's own table (inceptionv3.py:365-403)
+NN4_CONV_SHAPE = {
+    'conv1': (64, 3, 7, 7), 'conv2': (64, 64, 1, 1), 'conv3': (192, 64, 3, 3),
+    'inception_3a_1x1_conv': (64, 192, 1, 1), 'inception_3a_pool_conv': (32, 192, 1, 1),
+    'inception_3a_5x5_conv1': (16, 192, 1, 1), 'inception_3a_5x5_conv2': (32, 16, 5, 5),
+    'inception_3a_3x3_conv1': (96, 192, 1, 1), 'inception_3a_3x3_conv2': (128, 96, 3, 3),
+    'inception_3b_3x3_conv1': (96, 256, 1, 1), 'inception_3b_3x3_conv2': (128, 96, 3, 3),
+    'inception_3b_5x5_conv1': (32, 256, 1, 1), 'inception_3b_5x5_conv2': (64, 32, 5, 5),
+    'inception_3b_pool_conv': (64, 256, 1, 1), 'inception_3b_1x1_conv': (64, 256, 1, 1),
+    'inception_3c_3x3_conv1': (128, 320, 1, 1), 'inception_3c_3x3_conv2': (256, 128, 3, 3),
+    'inception_3c_5x5_conv1': (32, 320, 1, 1), 'inception_3c_5x5_conv2': (64, 32, 5, 5),
+    'inception_4a_3x3_conv1': (96, 640, 1, 1), 'inception_4a_3x3_conv2': (192, 96, 3, 3),
+    'inception_4a_5x5_conv1': (32, 640, 1, 1), 'inception_4a_5x5_conv2': (64, 32, 5, 5),
+    'inception_4a_pool_conv': (128, 640, 1, 1), 'inception_4a_1x1_conv': (256, 640, 1, 1),
+    'inception_4e_3x3_conv1': (160, 640, 1, 1), 'inception_4e_3x3_conv2': (256, 160, 3, 3),
+    'inception_4e_5x5_conv1': (64, 640, 1, 1), 'inception_4e_5x5_conv2': (128, 64, 5, 5),
+    'inception_5a_3x3_conv1': (96, 1024, 1, 1), 'inception_5a_3x3_conv2': (384, 96, 3, 3),
+    'inception_5a_pool_conv': (96, 1024, 1, 1), 'inception_5a_1x1_conv': (256, 1024, 1, 1),
+    'inception_5b_3x3_conv1': (96, 736, 1, 1), 'inception_5b_3x3_conv2': (384, 96, 3, 3),
+    'inception_5b_pool_conv': (96, 736, 1, 1), 'inception_5b_1x1_conv': (256, 736, 1, 1),
+}
+
+
+def nn4_spec(emd=128):
+    spec = []
+    for conv, (co, ci, kh, kw) in NN4_CONV_SHAPE.items():
+        spec += [(conv + '/kernel', (kh, kw, ci, co)), (conv + '/bias', (co,))]
+        bn = conv.replace('_conv', '_bn') if conv.startswith('inception') else conv.replace('conv', 'bn')
+        spec += [(bn + '/' + k, (co,)) for k in ('gamma', 'beta', 'moving_mean', 'moving_variance')]
+    spec += [('dense_layer/kernel', (736, emd)), ('dense_layer/bias', (emd,))]
+    return spec

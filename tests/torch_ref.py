@@ -94,3 +94,61 @@ def embed(x_nhwc, p, arch, head='v2'):
             return f.permute(0, 2, 3, 1).contiguous().numpy()
         layers = {'iresnet50': (3, 4, 14, 3), 'iresnet100': (3, 13, 30, 3)}[arch]
         return iresnet(x, p, layers).numpy()
+
+
+# ---------------------------------------------------------------------------- NN4.small2
+def _cbr(x, p, conv, bn, stride=1, pad=0):
+    y = _conv(x, p, conv, stride, pad)
+    return F.relu(_bn(y, p, bn, 1e-5))
+
+
+def _branch(x, p, layer, stride, pad):
+    return _cbr(_cbr(x, p, layer + '_conv1', layer + '_bn1'), p, layer + '_conv2', layer + '_bn2', stride, pad)
+
+
+def _lrn(x):
+    # torch divides alpha by the window size: alpha' = 1e-4 * 11 reproduces tf.nn.lrn(depth_radius=5)
+    return F.local_response_norm(x, size=11, alpha=11e-4, beta=0.75, k=1.0)
+
+
+def _l2pool(x):
+    return torch.sqrt(F.avg_pool2d(x * x, 3, 3) * 9)
+
+
+def nn4(x, p):
+    y = _cbr(x, p, 'conv1', 'bn1', 2, 3)
+    y = F.max_pool2d(F.pad(y, (1, 1, 1, 1)), 3, 2)
+    y = _lrn(y)
+    y = _cbr(y, p, 'conv2', 'bn2')
+    y = _cbr(y, p, 'conv3', 'bn3', 1, 1)
+    y = _lrn(y)
+    y = F.max_pool2d(F.pad(y, (1, 1, 1, 1)), 3, 2)
+    cat = lambda ts: torch.cat(ts, dim=1)   # noqa: E731
+    y = cat([_branch(y, p, 'inception_3a_3x3', 1, 1), _branch(y, p, 'inception_3a_5x5', 1, 2),
+             F.pad(_cbr(F.max_pool2d(y, 3, 2), p, 'inception_3a_pool_conv', 'inception_3a_pool_bn'), (3, 4, 3, 4)),
+             _cbr(y, p, 'inception_3a_1x1_conv', 'inception_3a_1x1_bn')])
+    y = cat([_branch(y, p, 'inception_3b_3x3', 1, 1), _branch(y, p, 'inception_3b_5x5', 1, 2),
+             F.pad(_cbr(_l2pool(y), p, 'inception_3b_pool_conv', 'inception_3b_pool_bn'), (4, 4, 4, 4)),
+             _cbr(y, p, 'inception_3b_1x1_conv', 'inception_3b_1x1_bn')])
+    y = cat([_branch(y, p, 'inception_3c_3x3', 2, 1), _branch(y, p, 'inception_3c_5x5', 2, 2),
+             F.pad(F.max_pool2d(y, 3, 2), (0, 1, 0, 1))])
+    y = cat([_branch(y, p, 'inception_4a_3x3', 1, 1), _branch(y, p, 'inception_4a_5x5', 1, 2),
+             F.pad(_cbr(_l2pool(y), p, 'inception_4a_pool_conv', 'inception_4a_pool_bn'), (2, 2, 2, 2)),
+             _cbr(y, p, 'inception_4a_1x1_conv', 'inception_4a_1x1_bn')])
+    y = cat([_branch(y, p, 'inception_4e_3x3', 2, 1), _branch(y, p, 'inception_4e_5x5', 2, 2),
+             F.pad(F.max_pool2d(y, 3, 2), (0, 1, 0, 1))])
+    y = cat([_branch(y, p, 'inception_5a_3x3', 1, 1),
+             F.pad(_cbr(_l2pool(y), p, 'inception_5a_pool_conv', 'inception_5a_pool_bn'), (1, 1, 1, 1)),
+             _cbr(y, p, 'inception_5a_1x1_conv', 'inception_5a_1x1_bn')])
+    y = cat([_branch(y, p, 'inception_5b_3x3', 1, 1),
+             F.pad(_cbr(F.max_pool2d(y, 3, 2), p, 'inception_5b_pool_conv', 'inception_5b_pool_bn'), (1, 1, 1, 1)),
+             _cbr(y, p, 'inception_5b_1x1_conv', 'inception_5b_1x1_bn')])
+    y = F.avg_pool2d(y, 3, 1).flatten(1)
+    y = y @ _t(p, 'dense_layer/kernel') + _t(p, 'dense_layer/bias')
+    return y / y.pow(2).sum(1, keepdim=True).clamp_min(1e-12).sqrt()
+
+
+def embed_nn4(x_nhwc, p):
+    x = torch.from_numpy(x_nhwc).permute(0, 3, 1, 2).contiguous()
+    with torch.no_grad():
+        return nn4(x, p).numpy()
