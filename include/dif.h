@@ -55,6 +55,15 @@ int dif_device_count(void);
 int dif_pairwise(const float* e1_dev, int64_t n1, const float* e2_dev, int64_t n2, int d, int metric,
                  float* out_dev, void* stream);
 
+/* LFW-protocol threshold sweep (evaluation/utility.py:36-49 calculate_accuracy and :69-77
+ * calculate_val_far, as looped by calculate_roc :153-161 and calculate_val :104-107): for every
+ * threshold t and test fold f, counts_dev[(f*T + t)*2 + 0/1] = number of pairs of fold f with
+ * dist < thresholds[t] that are same / different.  fold_dev[i] = fold whose test split holds
+ * pair i (KFold(shuffle=False): contiguous ranges). */
+int dif_threshold_counts(const float* dist_dev, const uint8_t* issame_dev, const int32_t* fold_dev, int64_t n,
+                         const double* thresholds_dev, int n_thresholds, int n_folds, int32_t* counts_dev,
+                         void* stream);
+
 /* ------------------------------------------------------------------ gallery + 1:N match
  * The reference has no 1:N entry point; the semantics are utility.distance broadcast
  * over gallery rows + np.argmin (first minimum).  Housed Python-side under
