@@ -59,7 +59,7 @@ def measured_traffic(workload, batch):
         return json.load(fh)['total']['conv_hbm_bytes_per_forward']
 
 
-def cpu_baseline(arch, head, gallery_rows, sample=16):
+def cpu_baseline(arch, head, gallery_rows, sample=96):
     """The oracle (NumPy port of the reference's algorithm) on a bounded sample of the same
     workload: `sample` faces embedded with the same synthetic weights + matched against the
     same-size gallery with the reference's distance formula."""
@@ -79,9 +79,10 @@ def cpu_baseline(arch, head, gallery_rows, sample=16):
     od.match(e, gal, 1)
     t2 = time.perf_counter()
     try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count()
+        from threadpoolctl import threadpool_info
+        cores = max([int(t.get('num_threads', 1)) for t in threadpool_info()] or [1])   # BLAS threads actually used
+    except Exception:
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
     return {
         'value': sample / (t2 - t0), 'unit': 'faces/s', 'cores': cores, 'kind': 'port',
         'sample': '%d faces: oracle embed (NumPy/BLAS, %.2fs) + reference-formula match vs %d rows (%.2fs)'

@@ -46,7 +46,8 @@ struct ConvALoader {
   int32_t base[N];   // byte offset of (n - n_first, hi0, wi0, 0) relative to the tile's first image (may be < 0)
   int32_t hw0[N];    // hi0 in the high 16 bits, wi0 in the low 16 bits (biased by 0x4000 each)
   int H, W, Cin, KW, taps;
-  FastDiv fd_cin, fd_kw;
+  FastDiv fd_cin, fd_kw, fd_taps;
+  int k_order;
   bool fast;         // Cin % 32 == 0: one (kh, kw) per K-step, block-uniform
   static constexpr int T_MAX_BM = 256;
 
@@ -65,6 +66,8 @@ struct ConvALoader {
     const int HoWo = a.Ho * a.Wo;
     fd_cin = a.fd_cin;
     fd_kw = a.fd_kw;
+    fd_taps = a.fd_taps;
+    k_order = a.k_order;
     const int n_first = a.fd_howo.div(m0);
     const int64_t img_elems = (int64_t)a.H * a.W * a.Cin;
     const int64_t imgs_left = a.N - n_first;
@@ -94,7 +97,13 @@ struct ConvALoader {
     bool tap_ok = true;
     if (fast) {
       int tap, ci0;
-      fd_cin.divmod(kstep * BK, tap, ci0);
+      if (k_order == 1) {
+        int cblk;
+        fd_taps.divmod(kstep, cblk, tap);
+        ci0 = cblk * BK;
+      } else {
+        fd_cin.divmod(kstep * BK, tap, ci0);
+      }
       fd_kw.divmod(tap, kh, kw);
       toff = ((kh * W + kw) * Cin + ci0) * 4;
       cch = ci0 + (threadIdx.x & 7) * 4;
@@ -403,6 +412,8 @@ static int launch_conv_pre(const ConvArgs& a, hipStream_t st) {
   b.fd_cin = make_fastdiv(a.Cin);
   b.fd_kw = make_fastdiv(a.KW);
   b.fd_ks = make_fastdiv(KS);
+  b.fd_taps = make_fastdiv(a.KH * a.KW);
+  if (a.k_order == 1 && a.Cin % BK != 0) return set_error("conv: channel-block-major K order needs Cin %% 32 == 0");
   b.fd_tiles_n = make_fastdiv((a.Cout + T::BN - 1) / T::BN);
   hipLaunchKernelGGL(kern, dim3((unsigned)P), dim3(T::NT), T::LDS_BYTES, st, b);
   DIF_HIP(hipGetLastError());

@@ -614,13 +614,16 @@ int Net::finalize(int mb) {
       const int taps = op.KH * op.KW;
       const int K = taps * op.Cin;
       op.Kpad = (K + BK - 1) / BK * BK;
+      static const int want_cbm = getenv("DIF_K_ORDER") ? atoi(getenv("DIF_K_ORDER")) : 1;
+      op.k_order = (want_cbm && taps > 1 && op.Cin % BK == 0 && op.Cin_true == op.Cin) ? 1 : 0;
       std::vector<float> packed((size_t)op.Cout * op.Kpad, 0.f);
       const float* w = params[op.w].data.data();   // [taps][Cin_true][Cout] (HWIO) or CHW-flattened dense
       for (int t = 0; t < taps; ++t)
         for (int ci = 0; ci < op.Cin_true; ++ci) {
           const int64_t src_row = op.chw_flatten ? ((int64_t)ci * taps + t) : ((int64_t)t * op.Cin_true + ci);
           const float* src = w + src_row * op.Cout;
-          for (int co = 0; co < op.Cout; ++co) packed[(size_t)co * op.Kpad + (size_t)t * op.Cin + ci] = src[co];
+          const size_t kk = op.k_order == 1 ? ((size_t)(ci / BK) * taps + t) * BK + ci % BK : (size_t)t * op.Cin + ci;
+          for (int co = 0; co < op.Cout; ++co) packed[(size_t)co * op.Kpad + kk] = src[co];
         }
       if (upload(this, packed, &op.d_w)) return -1;
       fold(this, op.bn, op.bias, op.Cout, &scale, &shift);
@@ -797,6 +800,7 @@ int Net::embed(const void* xin, int n, int layout, int dtype, float* out, hipStr
         a.pad_t = op.pad_t;
         a.pad_l = op.pad_l;
         a.Kpad = op.Kpad;
+        a.k_order = op.k_order;
         a.M = n * yd.H * yd.W;
         a.act = op.act;
         a.act2 = op.act2;

@@ -48,7 +48,8 @@ struct Op {
   int res_stride = 1;
   int zero_pad = 0;
   int pool_mode = POOL_MAX;
-  bool chw_flatten = false;   // dense after an NCHW-order flatten: permute kernel rows at pack time
+  bool chw_flatten = false;
+  int k_order = 0;            // see ConvArgs::k_order   // dense after an NCHW-order flatten: permute kernel rows at pack time
   // parameters
   int w = -1, bias = -1, alpha = -1, alpha2 = -1;
   BNRef bn, bn2;

@@ -40,7 +40,11 @@ inline FastDiv make_fastdiv(int d) {
 
 struct ConvArgs {
   const float* x;       // [N,H,W,Cin] NHWC
-  const float* w;       // packed [Cout][Kpad], k = (kh*KW + kw)*Cin + ci, zero padded
+  const float* w;       // packed [Cout][Kpad], zero padded; k order per k_order
+  int k_order;          // 0: k = (kh*KW + kw)*Cin + ci (tap-major)
+                        // 1: k = ((ci/32)*KH*KW + kh*KW + kw)*32 + ci%32 (channel-block-major, Cin % 32 == 0):
+                        //    consecutive K-steps sweep the taps of ONE 32-channel slice, i.e. re-read the
+                        //    same 128-byte lines of the same pixels -> L2 hits instead of fabric traffic
   float* y;             // [N,Ho,Wo,Cout]
   float* y2;            // optional second output (same shape) or null
   const float* scale;   // per Cout or null (= 1)
@@ -73,7 +77,7 @@ struct ConvArgs {
   int sk_max_blocks;
   int sk_spin_limit;    // polls before the owner computes a missing K range itself; < 0: always (test hook)
   // launch-invariant divisors (filled by conv_run)
-  FastDiv fd_howo, fd_wo, fd_cin, fd_kw, fd_ks, fd_tiles_n;
+  FastDiv fd_howo, fd_wo, fd_cin, fd_kw, fd_ks, fd_tiles_n, fd_taps;
 };
 
 int conv_max_blocks();        // persistent blocks the kernel may use on this device
