@@ -32,6 +32,8 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 namespace dif {
 
 // A-operand loader: gathers BM output pixels x 32 k-values per step.
@@ -149,6 +151,88 @@ struct ConvALoader {
   }
 };
 
+// LDS-DMA flavour of the gather (no pre-activation: the data never passes through registers).
+template <int N, int RP>
+struct ConvADmaLoader {
+  __amdgpu_buffer_rsrc_t rsrc;
+  int32_t base[N];
+  int32_t hw0[N];
+  int H, W, Cin, KW, taps;
+  FastDiv fd_cin, fd_kw, fd_taps;
+  int k_order, chunk;   // chunk = the global 16-byte chunk this thread's LDS slot receives
+  bool fast;
+
+  __device__ __forceinline__ ConvADmaLoader(const ConvArgs& a, int m0) {
+    const int tid = threadIdx.x;
+    H = a.H;
+    W = a.W;
+    Cin = a.Cin;
+    KW = a.KW;
+    taps = a.KH * a.KW;
+    fast = (a.Cin % BK) == 0;
+    fd_cin = a.fd_cin;
+    fd_kw = a.fd_kw;
+    fd_taps = a.fd_taps;
+    k_order = a.k_order;
+    chunk = (tid & 7) ^ dma_swizzle(tid >> 3);
+    const int HoWo = a.Ho * a.Wo;
+    const int n_first = a.fd_howo.div(m0);
+    const int64_t img_elems = (int64_t)a.H * a.W * a.Cin;
+    const int64_t imgs_left = a.N - n_first;
+    int64_t span = (256 + HoWo - 1) / HoWo + 1;
+    if (span > imgs_left) span = imgs_left;
+    rsrc = make_rsrc(a.x + n_first * img_elems, (uint32_t)(span * img_elems * 4));
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int m = m0 + (tid >> 3) + RP * i;
+      if (m < a.M) {
+        int n, r, ho, wo;
+        a.fd_howo.divmod(m, n, r);
+        a.fd_wo.divmod(r, ho, wo);
+        const int hi0 = ho * a.stride - a.pad_t;
+        const int wi0 = wo * a.stride - a.pad_l;
+        base[i] = (int32_t)((((int64_t)(n - n_first) * a.H + hi0) * a.W + wi0) * a.Cin * 4) + chunk * 16;
+        hw0[i] = ((hi0 + 0x4000) << 16) | (wi0 + 0x4000);
+      } else {
+        base[i] = 0;
+        hw0[i] = 0;
+      }
+    }
+  }
+
+  __device__ __forceinline__ void issue(int kstep, float* lds_tile) const {
+    int kh, kw, toff;
+    bool tap_ok = true;
+    if (fast) {
+      int tap, ci0;
+      if (k_order == 1) {
+        int cblk;
+        fd_taps.divmod(kstep, cblk, tap);
+        ci0 = cblk * BK;
+      } else {
+        fd_cin.divmod(kstep * BK, tap, ci0);
+      }
+      fd_kw.divmod(tap, kh, kw);
+      toff = ((kh * W + kw) * Cin + ci0) * 4;
+    } else {
+      int tap, ci;
+      fd_cin.divmod(kstep * BK + chunk * 4, tap, ci);
+      fd_kw.divmod(tap, kh, kw);
+      tap_ok = tap < taps;
+      toff = ((kh * W + kw) * Cin + ci) * 4 - chunk * 16;
+    }
+    const int wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int hi = (hw0[i] >> 16) - 0x4000 + kh;
+      const int wi = (hw0[i] & 0xffff) - 0x4000 + kw;
+      const bool ok = tap_ok && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+      const uint32_t off = ok ? (uint32_t)(base[i] + toff) : OOB;
+      dma_load16(rsrc, lds_tile + (wave * 8 + RP * i) * BK, off);
+    }
+  }
+};
+
 __device__ __forceinline__ float apply_act(float v, int act, float alpha) {
   if (act == ACT_RELU) return fmaxf(v, 0.f);
   if (act == ACT_PRELU) return v >= 0.f ? v : v * alpha;
@@ -250,8 +334,9 @@ __device__ __forceinline__ int xcd_remap(int b, int P) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }
 
-template <class T, bool PRE>
+template <class T, bool PRE, bool DMA>
 __global__ __launch_bounds__(T::NT, 2) void conv_igemm_kernel(const ConvArgs a) {
+  static_assert(!(PRE && DMA), "pre-activation needs register staging");
   constexpr int WM = T::WM, WN = T::WN;
   constexpr int SLAB = T::BM * T::BN;    // floats per partial-accumulator slab
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -276,9 +361,18 @@ __global__ __launch_bounds__(T::NT, 2) void conv_igemm_kernel(const ConvArgs a) 
 
     f32x16 acc[WM][WN];
     zero_acc<T>(acc);
-    ConvALoader<T::NA, T::RP, PRE> al(a, m0);
-    RowLoader<T::NB, T::RP> bl(a.w + (int64_t)n0 * a.Kpad, (int64_t)a.Cout - n0, a.Kpad);
-    gemm_mainloop<T>(al, bl, kb, ke, smem, acc);
+    // pre-activation needs the operand in registers; everything else streams through LDS-DMA
+    using ALoad = typename std::conditional<DMA, ConvADmaLoader<T::NA, T::RP>, ConvALoader<T::NA, T::RP, PRE>>::type;
+    using BLoad = typename std::conditional<DMA, DmaRowLoader<T::NB, T::RP>, RowLoader<T::NB, T::RP>>::type;
+    ALoad al(a, m0);
+    BLoad bl(a.w + (int64_t)n0 * a.Kpad, (int64_t)a.Cout - n0, a.Kpad);
+    auto run = [&](int k0, int k1) {
+      if constexpr (DMA)
+        gemm_mainloop_dma<T>(al, bl, k0, k1, smem, acc);
+      else
+        gemm_mainloop<T>(al, bl, k0, k1, smem, acc);
+    };
+    run(kb, ke);
 
     if (kb != 0) {
       // not the owner of this tile: publish the partial accumulators (fragment order, 16 B per lane)
@@ -342,7 +436,7 @@ __global__ __launch_bounds__(T::NT, 2) void conv_igemm_kernel(const ConvArgs a) 
         } else {
           // the partner never showed up (not co-resident): compute its K range here instead of
           // waiting for ever -- slower, still correct
-          gemm_mainloop<T>(al, bl, q_kb, q_ke, smem, acc);
+          run(q_kb, q_ke);
         }
         kdone = q_ke;
       }
@@ -368,19 +462,23 @@ static int num_cus() {
 int conv_max_blocks() { return 4 * num_cus(); }
 size_t conv_slab_floats() { return 128 * 128; }
 
-template <class T, bool PRE>
+template <class T, bool PRE, bool DMA>
 static int launch_conv_pre(const ConvArgs& a, hipStream_t st);
 
 template <class T>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
-  if (a.pre_scale) return launch_conv_pre<T, true>(a, st);
-  return launch_conv_pre<T, false>(a, st);
+  // LDS-DMA operand staging is +1..5 % on the plain GEMM microbenchmark but -1.2 % inside this
+  // kernel (interleaved A/B, both networks), so register staging stays the default.
+  static const bool use_dma = getenv("DIF_USE_DMA") && atoi(getenv("DIF_USE_DMA"));
+  if (a.pre_scale) return launch_conv_pre<T, true, false>(a, st);
+  if (use_dma) return launch_conv_pre<T, false, true>(a, st);
+  return launch_conv_pre<T, false, false>(a, st);
 }
 
-template <class T, bool PRE>
+template <class T, bool PRE, bool DMA>
 static int launch_conv_pre(const ConvArgs& a, hipStream_t st) {
   static bool attr_set = false;
-  auto kern = conv_igemm_kernel<T, PRE>;
+  auto kern = conv_igemm_kernel<T, PRE, DMA>;
   if (!attr_set) {
     DIF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 T::LDS_BYTES));

@@ -16,6 +16,8 @@
 #include "gemm_core.hpp"
 #include "dif_internal.hpp"
 
+#include <stdlib.h>
+
 namespace dif {
 
 __device__ __forceinline__ bool better(float k, int i, float bk, int bi) {
@@ -277,13 +279,24 @@ static int launch_match_tiles(const Gallery* g, const float* probes, int B, int 
   return 0;
 }
 
+static int match_tile_kind(int B) {
+  // 0: 128 gallery rows x 128 probes, 1: 128 x 64, 3: 64 x 64
+  static const int forced = getenv("DIF_MATCH_TILE") ? atoi(getenv("DIF_MATCH_TILE")) : -1;
+  if (forced >= 0) return forced;
+  // unlike the convolutions, the 128-row tiles win here (the arg-min epilogue and the probe
+  // re-reads weigh more on small tiles: 117 vs 99 TF at 256 x 1M, 128 vs 120 TF at 4096 x 125k)
+  return B <= 64 ? 1 : 0;
+}
+
 int match_plan_parts(const Gallery* g, int B) {
-  // one partial row per persistent block column; enough blocks to fill 256 CUs x 2
-  const int BM = 128;
+  // One gallery tile per block while the partial buffer stays small; beyond that the blocks
+  // stride over tiles (the imbalance of a long stride is negligible).
+  const int kind = match_tile_kind(B);
+  const int BM = kind == 3 ? 64 : 128;
   const int64_t gtiles = (g->n + BM - 1) / BM;
-  const int ptiles = (B + 127) / 128;
-  int64_t want = (512 + ptiles - 1) / ptiles * 2;   // ~4 blocks per CU in flight across the grid
-  if (want > gtiles) want = gtiles;
+  int64_t cap = (int64_t)(32 << 20) / ((int64_t)B * 8);   // <= 32 MiB of (key, idx) partials
+  if (cap < 1024) cap = 1024;
+  int64_t want = gtiles < cap ? gtiles : cap;
   if (want < 1) want = 1;
   return (int)want;
 }
@@ -305,7 +318,10 @@ int match_run(Gallery* g, const float* probes, int B, int metric, int64_t* idx_o
     g->part_cap = need;
   }
   int rc;
-  if (B <= 64)
+  const int kind = match_tile_kind(B);
+  if (kind == 3)
+    rc = launch_match_tiles<Tile<1, 1>>(g, probes, B, metric, nparts, st);
+  else if (kind == 1 || B <= 64)
     rc = launch_match_tiles<Tile<2, 1>>(g, probes, B, metric, nparts, st);
   else
     rc = launch_match_tiles<Tile<2, 2>>(g, probes, B, metric, nparts, st);
