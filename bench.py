@@ -39,7 +39,12 @@ WORKLOADS = {
             'configs[1]: ResNet-50V2+GDC 512-d embed, batch=256/GPU, 100k gallery cosine match'),
     'r100': ('iresnet100', 'v2', 256, 100_000,
              'north_star target: IResNet-100 512-d embed, batch=256/GPU, 100k gallery cosine match'),
+    'r100_arc': ('iresnet100', 'v2', 512, 100_000,
+                 'configs[2]: IResNet-100 512-d embed + ArcMargin logits (85742 classes), batch=512/GPU'),
+    'r100_1m': ('iresnet100', 'v2', 512, 1_000_000,
+                'configs[3]: IResNet-100 embed, batch=512/GPU (4096 on 8 GPUs), 1M gallery row-sharded'),
 }
+ARC_CLASSES = 85_742     # MS1MV2 identities
 
 
 def synthetic_gallery(rows, d, seed, device):
@@ -129,6 +134,12 @@ def main():
     gal_full = synthetic_gallery(gallery_rows, 512, 7, 'cpu')
     shard = ShardedGallery(gal_full[lo:hi].to(dev), lo)
     del gal_full
+    arc = None
+    if args.workload == 'r100_arc':
+        from deep_insight_face.networks.arcmargin import ArcMarginHead
+        gw = torch.Generator(device='cpu').manual_seed(99)
+        arc = ArcMarginHead(torch.randn((ARC_CLASSES, 512), generator=gw).to(dev))
+        arc_labels = torch.randint(0, ARC_CLASSES, (batch,), generator=gw).to(dev)
     g = torch.Generator(device='cpu').manual_seed(1234 + rank)
     crops = torch.randint(0, 256, (batch, 112, 112, 3), generator=g, dtype=torch.uint8).to(dev)
 
@@ -140,6 +151,8 @@ def main():
         emb = model.embed(crops)
         if i is not None:
             ev[i][1].record()
+        if arc is not None:
+            arc.logits(emb, arc_labels)
         idx, d = shard.match(emb, 1)
         if i is not None:
             ev[i][2].record()

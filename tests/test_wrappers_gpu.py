@@ -1,0 +1,108 @@
+"""The reference-signature wrappers (predictions.py, api.py, evaluation/evals.py,
+networks/utils.py) on top of the HIP path, against the oracle's restatement of the same
+reference lines."""
+import numpy as np
+import pytest
+
+from oracle import distance as od
+from oracle import nets
+
+pytestmark = pytest.mark.gpu
+
+
+def crops_u8(n, hw=112, seed=1234):
+    return np.random.default_rng(seed).integers(0, 256, (n, hw, hw, 3), dtype=np.uint8)
+
+
+def cosine_gap(a, b):
+    a = a.reshape(a.shape[0], -1).astype(np.float64)
+    b = b.reshape(b.shape[0], -1).astype(np.float64)
+    return 1.0 - (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+
+
+@pytest.fixture(scope='module')
+def model():
+    from deep_insight_face.networks.triplet import bottleneck_network
+    m = bottleneck_network('resnet', 128, (112, 112, 3), max_batch=8)('v2').init_synthetic(7)
+    yield m
+    m.close()
+
+
+def test_triplet_prediction(cuda, model, capsys):
+    from deep_insight_face.predictions import TripletPrediction
+    p = model.get_weights()
+    tp = TripletPrediction(model, img_size=(112, 112))
+    assert TripletPrediction(model, img_size=(112, 112)) is tp          # singleton per class (predictions.py:27-31)
+    img = crops_u8(1, seed=3)[0]
+    emb = tp._embedding(img)                                             # image * 1/255 -> predict_on_batch
+    want = nets.embed(img[None].astype(np.float32) / np.float32(255), p, 'resnet', 128, 'v2')
+    assert emb.shape == (1, 128) and cosine_gap(emb, want).max() < 1e-5
+    with pytest.raises(AssertionError, match='Invalid image format'):
+        tp._embedding('not-an-array')
+    db = {'alice': want[0], 'bob': -want[0]}
+    d, ok = tp.verify(img, 'alice', db, threshold=0.7)
+    assert ok and d < 1e-2
+    d, ok = tp.verify(img, 'bob', db, threshold=0.7)
+    assert (not ok) and abs(d - 2.0) < 1e-3
+    out = capsys.readouterr().out
+    assert "It's alice" in out and "It's not bob" in out
+    batch = tp._embedding_batch(list(crops_u8(3, seed=4)))
+    assert batch.shape == (3, 128)
+
+
+def test_siamese_prediction_applies_vgg_preprocess(cuda, model):
+    from deep_insight_face.predictions import SiamesePrediction
+    p = model.get_weights()
+    sp = SiamesePrediction(model, img_size=(112, 112))
+    img = crops_u8(1, seed=8)[0]
+    emb = sp._embedding(img)
+    x = img[None].astype(np.float32) / np.float32(255)
+    mean = np.array([103.939, 116.779, 123.68], dtype=np.float32)
+    want = nets.embed(x[..., ::-1] - mean, p, 'resnet', 128, 'v2')      # keras vgg16.preprocess_input, caffe mode
+    assert cosine_gap(emb, want).max() < 1e-5
+    db = {'carol': [want[0], want[0]]}
+    d, ok = sp.verify(img, 'carol', db, threshold=0.3)
+    assert ok and d < 1e-2
+
+
+def test_api_distances(cuda):
+    from deep_insight_face import api
+    from deep_insight_face.networks import utils as nu
+    rng = np.random.default_rng(0)
+    a, b = rng.standard_normal(128).astype(np.float32), rng.standard_normal(128).astype(np.float32)
+    assert api.face_distance([], b).shape == (0,)
+    np.testing.assert_allclose(api.face_distance(a, b), od.face_distance(a, b), rtol=1e-6)
+    A = rng.standard_normal((5, 128)).astype(np.float32)
+    np.testing.assert_allclose(api.face_distance(A, b), od.face_distance(A, b), rtol=1e-5)   # axis-0 quirk kept
+    for scale in (0.01, 1.0):
+        d, pr = api.compare_faces([a * scale], [b * scale])
+        od_, opr = od.compare_faces([a * scale], [b * scale])
+        np.testing.assert_allclose([d, pr], [od_, opr], rtol=1e-5)
+    np.testing.assert_allclose(nu.distance(a, b), od.sq_l2(a, b), rtol=1e-6)
+    assert nu.distance_to_proba(0.5) == od.distance_to_proba(0.5)
+    assert nu.gaussian_kernel_dist_to_prob(0.5, 2.0) == od.gaussian_kernel_dist_to_prob(0.5, 2.0)
+    from deep_insight_face.exceptions import FaceRecognitionException
+    with pytest.raises(FaceRecognitionException):
+        api.face_encodings(np.zeros((112, 112, 3), np.uint8), (112, 112, 3))    # detector is out of scope
+
+
+def test_api_face_encodings_with_registered_model(cuda, model):
+    from deep_insight_face import api
+    api.set_face_recognition_model(model, 'triplet')
+    img = crops_u8(1, seed=5)[0]
+    thumb, enc = api.face_encodings(img, (112, 112, 3), detect_and_crop=False)
+    assert thumb[0] is img and enc.shape == (1, 128)
+    np.testing.assert_allclose(np.linalg.norm(enc), 1.0, atol=1e-5)
+
+
+def test_batched_eval_loop(cuda, model):
+    """evaluation/evals.py:53-59: predict_on_batch per batch scattered into one array."""
+    from deep_insight_face.evaluation.evals import embed_batches
+    x = crops_u8(10, seed=6).astype(np.float32) / np.float32(255)
+    batches = [(x[0:4], np.arange(0, 4)), (x[4:8], np.arange(4, 8)), (x[8:10], np.arange(8, 10))]
+    emb, lab = embed_batches(model, batches, 10, 128)
+    assert emb.shape == (10, 128) and emb.dtype == np.float64
+    whole = model.predict_on_batch(x[:8])
+    assert cosine_gap(emb[:8], whole).max() < 1e-6
+    with pytest.raises(AssertionError, match='Wrong labels'):
+        embed_batches(model, [(x[0:4], np.array([0, 1, 2, 5]))], 4, 128)
