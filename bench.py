@@ -104,6 +104,9 @@ def main():
     ap.add_argument('--batch', type=int, default=0, help='per-GPU batch override')
     ap.add_argument('--gallery', type=int, default=0, help='total gallery rows override')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='gloo = rehearsal of the N>1 path on a box with fewer GPUs than ranks (collectives staged '
+                         'through the host, ranks share devices); never used for reported numbers')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -115,11 +118,29 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit('bench.py needs a HIP device: the hot path has no CPU fallback')
+    if args.backend == 'gloo':
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)   # RCCL over xGMI
+        else:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+            _orig_ag, _orig_ar = dist.all_gather_into_tensor, dist.all_reduce
+
+            def _ag(out, inp, group=None):
+                o = torch.empty(out.shape, dtype=out.dtype)
+                _orig_ag(o, inp.cpu(), group=group)
+                out.copy_(o)
+
+            def _ar(t, op=dist.ReduceOp.SUM, group=None):
+                c = t.cpu()
+                _orig_ar(c, op=op, group=group)
+                t.copy_(c)
+
+            dist.all_gather_into_tensor, dist.all_reduce = _ag, _ar
 
     from deep_insight_face.networks.triplet import DifEmbedder
     from deep_insight_face.parallel import ShardedGallery, shard_bounds
@@ -202,7 +223,7 @@ def main():
             'config': {'workload': desc, 'arch': arch, 'head': head, 'batch_per_gpu': batch,
                        'global_batch': world * batch, 'gallery_rows': gallery_rows,
                        'gallery_rows_per_gpu': hi - lo, 'emd': 512, 'metric': 'cosine',
-                       'parallelism': 'dp%d + gallery row-shard' % world},
+                       'parallelism': 'dp%d + gallery row-shard' % world, 'backend': args.backend if world > 1 else None},
             'phases_ms': {'embed': embed_ms, 'match': match_ms},
             'roofline': {
                 'bound': 'mfma', 'kernel': 'conv_igemm_kernel (f32 MFMA implicit-GEMM conv; one launch group = the '
