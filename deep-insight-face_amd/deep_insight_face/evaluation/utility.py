@@ -209,3 +209,6 @@ def evaluate(embeddings, labels, nrof_folds=10, distance_metric=0, subtract_mean
                                       nrof_folds=nrof_folds, distance_metric=distance_metric,
                                       subtract_mean=subtract_mean)
     return tpr, fpr, accuracy, f1scores, val, val_std, far
+
+
+from .pairs import add_extension, get_paths, read_pairs  # noqa: E402,F401  (utility.py:222-262)
