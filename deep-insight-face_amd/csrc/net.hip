@@ -33,9 +33,15 @@ static const float EPS_IRESNET = 1e-5f;      // torch BatchNorm default
 Net::~Net() { release_device(); }
 
 void Net::release_device() {
+  for (Lane& L : lanes) {
+    if (L.stream) (void)hipStreamDestroy(L.stream);
+    if (L.done) (void)hipEventDestroy(L.done);
+  }
+  lanes.clear();
+  if (ev_start) (void)hipEventDestroy(ev_start);
+  ev_start = nullptr;
   for (void* p : allocs) (void)hipFree(p);
   allocs.clear();
-  bufs.clear();
   finalized = false;
 }
 
@@ -688,24 +694,36 @@ int Net::finalize(int mb) {
       }
   }
   sk_max_blocks = conv_max_blocks();
-  {
+  if (const char* e = getenv("DIF_SK_SPIN_LIMIT")) sk_spin_limit = atoi(e);   // test hook (tests/test_embed_gpu.py)
+  int nl = getenv("DIF_STREAMS") ? atoi(getenv("DIF_STREAMS")) : 2;
+  if (nl < 1) nl = 1;
+  if (nl > 8) nl = 8;
+  if (max_batch < 64 * nl) nl = 1;
+  lanes.assign(nl, Lane());
+  DIF_HIP(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
+  for (int l = 0; l < nl; ++l) {
+    Lane& L = lanes[l];
+    L.cap = l == 0 ? max_batch : (max_batch + nl - 1) / nl;   // lane 0 also serves unsplit and profiled forwards
+    if (l > 0) {
+      DIF_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+      DIF_HIP(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
+    }
     void* d = nullptr;
     DIF_HIP(hipMalloc(&d, (size_t)sk_max_blocks * conv_slab_floats() * sizeof(float)));
     allocs.push_back(d);
-    sk_slab = static_cast<float*>(d);
+    L.sk_slab = static_cast<float*>(d);
     DIF_HIP(hipMalloc(&d, (size_t)sk_max_blocks * sizeof(unsigned)));
     allocs.push_back(d);
-    sk_flag = static_cast<unsigned*>(d);
-    DIF_HIP(hipMemset(sk_flag, 0, (size_t)sk_max_blocks * sizeof(unsigned)));
-    sk_epoch = 0;
-    if (const char* e = getenv("DIF_SK_SPIN_LIMIT")) sk_spin_limit = atoi(e);   // test hook (tests/test_embed_gpu.py)
-  }
-  bufs.assign(buf_elems.size(), nullptr);
-  for (size_t b = 0; b < buf_elems.size(); ++b) {
-    float* d = nullptr;
-    DIF_HIP(hipMalloc(&d, (size_t)buf_elems[b] * max_batch * sizeof(float)));
-    allocs.push_back(d);
-    bufs[b] = d;
+    L.sk_flag = static_cast<unsigned*>(d);
+    DIF_HIP(hipMemset(L.sk_flag, 0, (size_t)sk_max_blocks * sizeof(unsigned)));
+    L.sk_epoch = 0;
+    L.bufs.assign(buf_elems.size(), nullptr);
+    for (size_t b = 0; b < buf_elems.size(); ++b) {
+      float* f = nullptr;
+      DIF_HIP(hipMalloc(&f, (size_t)buf_elems[b] * L.cap * sizeof(float)));
+      allocs.push_back(f);
+      L.bufs[b] = f;
+    }
   }
   finalized = true;
   return 0;
@@ -730,6 +748,171 @@ const char* Net::kernel_name(const Op& op, int n) const {
   return "?";
 }
 
+// One layer op of one lane (a lane = its own activation buffers + stream-K workspace).
+int Net::run_op(const Op& op, Lane& L, const void* xin, int n, int layout, int dtype, float* out, hipStream_t st) {
+  auto ptr = [&](int t) -> float* {
+    if (t < 0) return nullptr;
+    if (t == output_tensor) return out;
+    return L.bufs[tensors[root_of(t)].buf];
+  };
+  switch (op.kind) {
+    case OP_INPUT: {
+      InputArgs a;
+      a.x = xin;
+      a.y = ptr(op.y);
+      a.N = n;
+      a.H = in_h;
+      a.W = in_w;
+      a.layout = layout;
+      a.dtype = dtype;
+      a.scale = in_scale;
+      a.bias[0] = in_bias[0];
+      a.bias[1] = in_bias[1];
+      a.bias[2] = in_bias[2];
+      a.bgr = bgr;
+      if (input_convert_run(a, st)) return -1;
+      break;
+    }
+    case OP_CONV: {
+      const TensorDesc& xd = tensors[op.x];
+      const TensorDesc& yd = tensors[op.y >= 0 ? op.y : op.y2];
+      ConvArgs a;
+      memset(&a, 0, sizeof(a));
+      a.x = ptr(op.x);
+      a.w = op.d_w;
+      a.y = ptr(op.y);
+      a.y2 = ptr(op.y2);
+      a.scale = op.d_scale;
+      a.shift = op.d_shift;
+      a.alpha = op.d_alpha;
+      a.res = ptr(op.res);
+      a.scale2 = op.d_scale2;
+      a.shift2 = op.d_shift2;
+      a.alpha2 = op.d_alpha2;
+      a.pre_scale = op.d_pre_scale;
+      a.pre_shift = op.d_pre_shift;
+      a.pre_act = op.pre_act;
+      a.N = n;
+      a.H = xd.H;
+      a.W = xd.W;
+      a.Cin = op.Cin;
+      a.Ho = yd.H;
+      a.Wo = yd.W;
+      a.Cout = op.Cout;
+      a.KH = op.KH;
+      a.KW = op.KW;
+      a.stride = op.stride;
+      a.pad_t = op.pad_t;
+      a.pad_l = op.pad_l;
+      a.Kpad = op.Kpad;
+      a.k_order = op.k_order;
+      a.M = n * yd.H * yd.W;
+      a.act = op.act;
+      a.act2 = op.act2;
+      if (op.res >= 0) {
+        a.res_H = tensors[op.res].H;
+        a.res_W = tensors[op.res].W;
+        a.res_stride = op.res_stride;
+      } else {
+        a.res_H = yd.H;
+        a.res_W = yd.W;
+        a.res_stride = 1;
+      }
+      {
+        const TensorDesc& vd = tensors[op.y >= 0 ? op.y : op.y2];
+        if (vd.parent >= 0) {
+          const TensorDesc& pd = tensors[vd.parent];
+          a.y_ld = pd.C;
+          a.y_coff = vd.coff;
+          a.y_H = pd.H;
+          a.y_W = pd.W;
+          a.y_oy = vd.oy;
+          a.y_ox = vd.ox;
+        } else {
+          a.y_ld = op.Cout;
+          a.y_coff = 0;
+          a.y_H = yd.H;
+          a.y_W = yd.W;
+          a.y_oy = a.y_ox = 0;
+        }
+      }
+      a.sk_slab = L.sk_slab;
+      a.sk_flag = L.sk_flag;
+      a.sk_max_blocks = sk_max_blocks;
+      a.sk_epoch = ++L.sk_epoch;
+      a.sk_spin_limit = sk_spin_limit;
+      if (conv_run(a, -1, st)) return -1;
+      break;
+    }
+    case OP_MAXPOOL: {
+      const TensorDesc& xd = tensors[op.x];
+      const TensorDesc& yd = tensors[op.y];
+      PoolArgs a;
+      memset(&a, 0, sizeof(a));
+      a.x = ptr(op.x);
+      a.y = ptr(op.y);
+      a.y2 = ptr(op.y2);
+      a.scale2 = op.d_scale2;
+      a.shift2 = op.d_shift2;
+      a.N = n;
+      a.H = xd.H;
+      a.W = xd.W;
+      a.C = xd.C;
+      a.Ho = yd.H;
+      a.Wo = yd.W;
+      a.k = op.KH;
+      a.stride = op.stride;
+      a.pad_t = op.pad_t;
+      a.pad_l = op.pad_l;
+      a.zero_pad = op.zero_pad;
+      a.act2 = op.act2;
+      a.mode = op.pool_mode;
+      if (yd.parent >= 0) {
+        const TensorDesc& pd = tensors[yd.parent];
+        a.y_ld = pd.C;
+        a.y_coff = yd.coff;
+        a.y_H = pd.H;
+        a.y_W = pd.W;
+        a.y_oy = yd.oy;
+        a.y_ox = yd.ox;
+      } else {
+        a.y_ld = yd.C;
+        a.y_coff = 0;
+        a.y_H = yd.H;
+        a.y_W = yd.W;
+        a.y_oy = a.y_ox = 0;
+      }
+      if (maxpool_run(a, st)) return -1;
+      break;
+    }
+    case OP_DWFULL: {
+      const TensorDesc& xd = tensors[op.x];
+      if (dwfull_run(ptr(op.x), op.d_w, op.d_scale, op.d_shift, ptr(op.y), n, xd.H * xd.W, xd.C, st)) return -1;
+      break;
+    }
+    case OP_LRN: {
+      const TensorDesc& xd = tensors[op.x];
+      // tf.nn.lrn defaults: depth_radius 5, bias 1; alpha / beta from inceptionv3.py:95
+      if (lrn_run(ptr(op.x), ptr(op.y), (int64_t)n * xd.H * xd.W, xd.C, 5, 1.f, 1e-4f, 0.75f, st)) return -1;
+      break;
+    }
+    case OP_ZERO: {
+      const TensorDesc& yd = tensors[op.y];
+      DIF_HIP(hipMemsetAsync(ptr(op.y), 0, (size_t)n * yd.elems() * sizeof(float), st));
+      break;
+    }
+    case OP_L2NORM:
+      if (l2norm_run(ptr(op.x), ptr(op.y), n, op.Cout, 1e-12f, st)) return -1;
+      break;
+  }
+  return 0;
+}
+
+// Forward.  Batches of >= 64 images are split over the lanes: lane 0 runs on the caller's
+// stream, the others on internal HIP streams, layer by layer in lock-step order of submission.
+// Every convolution launch fills the chip, so the lanes mostly alternate; what overlaps is each
+// kernel's tail (its last, partly filled round of blocks) with the head of the other lane's
+// kernel -- measured +2..3 % on both networks at batch 256 (tools/two_streams.py).
 int Net::embed(const void* xin, int n, int layout, int dtype, float* out, hipStream_t st, float* op_ms) {
   if (!finalized) return set_error("dif_net_embed: call dif_net_finalize first");
   if (n < 0 || n > max_batch) return set_error("dif_net_embed: batch %d outside [0, max_batch=%d]", n, max_batch);
@@ -737,176 +920,50 @@ int Net::embed(const void* xin, int n, int layout, int dtype, float* out, hipStr
   if (!xin || !out) return set_error("dif_net_embed: null pointer");
   if (layout != DIF_LAYOUT_NHWC && layout != DIF_LAYOUT_NCHW) return set_error("dif_net_embed: bad layout %d", layout);
   if (dtype != DIF_DTYPE_F32 && dtype != DIF_DTYPE_U8) return set_error("dif_net_embed: bad dtype %d", dtype);
-  auto ptr = [&](int t) -> float* {
-    if (t < 0) return nullptr;
-    if (t == output_tensor) return out;
-    return bufs[tensors[root_of(t)].buf];
-  };
-  std::vector<hipEvent_t> ev;
-  if (op_ms) {
-    ev.resize(ops.size() + 1);
-    for (auto& e : ev) DIF_HIP(hipEventCreate(&e));
-    DIF_HIP(hipEventRecord(ev[0], st));
-  }
-  int op_index = 0;
-  for (const Op& op : ops) {
-    switch (op.kind) {
-      case OP_INPUT: {
-        InputArgs a;
-        a.x = xin;
-        a.y = ptr(op.y);
-        a.N = n;
-        a.H = in_h;
-        a.W = in_w;
-        a.layout = layout;
-        a.dtype = dtype;
-        a.scale = in_scale;
-        a.bias[0] = in_bias[0];
-        a.bias[1] = in_bias[1];
-        a.bias[2] = in_bias[2];
-        a.bgr = bgr;
-        if (input_convert_run(a, st)) return -1;
-        break;
-      }
-      case OP_CONV: {
-        const TensorDesc& xd = tensors[op.x];
-        const TensorDesc& yd = tensors[op.y >= 0 ? op.y : op.y2];
-        ConvArgs a;
-        memset(&a, 0, sizeof(a));
-        a.x = ptr(op.x);
-        a.w = op.d_w;
-        a.y = ptr(op.y);
-        a.y2 = ptr(op.y2);
-        a.scale = op.d_scale;
-        a.shift = op.d_shift;
-        a.alpha = op.d_alpha;
-        a.res = ptr(op.res);
-        a.scale2 = op.d_scale2;
-        a.shift2 = op.d_shift2;
-        a.alpha2 = op.d_alpha2;
-        a.pre_scale = op.d_pre_scale;
-        a.pre_shift = op.d_pre_shift;
-        a.pre_act = op.pre_act;
-        a.N = n;
-        a.H = xd.H;
-        a.W = xd.W;
-        a.Cin = op.Cin;
-        a.Ho = yd.H;
-        a.Wo = yd.W;
-        a.Cout = op.Cout;
-        a.KH = op.KH;
-        a.KW = op.KW;
-        a.stride = op.stride;
-        a.pad_t = op.pad_t;
-        a.pad_l = op.pad_l;
-        a.Kpad = op.Kpad;
-        a.k_order = op.k_order;
-        a.M = n * yd.H * yd.W;
-        a.act = op.act;
-        a.act2 = op.act2;
-        if (op.res >= 0) {
-          a.res_H = tensors[op.res].H;
-          a.res_W = tensors[op.res].W;
-          a.res_stride = op.res_stride;
-        } else {
-          a.res_H = yd.H;
-          a.res_W = yd.W;
-          a.res_stride = 1;
-        }
-        {
-          const TensorDesc& vd = tensors[op.y >= 0 ? op.y : op.y2];
-          if (vd.parent >= 0) {
-            const TensorDesc& pd = tensors[vd.parent];
-            a.y_ld = pd.C;
-            a.y_coff = vd.coff;
-            a.y_H = pd.H;
-            a.y_W = pd.W;
-            a.y_oy = vd.oy;
-            a.y_ox = vd.ox;
-          } else {
-            a.y_ld = op.Cout;
-            a.y_coff = 0;
-            a.y_H = yd.H;
-            a.y_W = yd.W;
-            a.y_oy = a.y_ox = 0;
-          }
-        }
-        a.sk_slab = sk_slab;
-        a.sk_flag = sk_flag;
-        a.sk_max_blocks = sk_max_blocks;
-        a.sk_epoch = ++sk_epoch;
-        a.sk_spin_limit = sk_spin_limit;
-        if (conv_run(a, -1, st)) return -1;
-        break;
-      }
-      case OP_MAXPOOL: {
-        const TensorDesc& xd = tensors[op.x];
-        const TensorDesc& yd = tensors[op.y];
-        PoolArgs a;
-        memset(&a, 0, sizeof(a));
-        a.x = ptr(op.x);
-        a.y = ptr(op.y);
-        a.y2 = ptr(op.y2);
-        a.scale2 = op.d_scale2;
-        a.shift2 = op.d_shift2;
-        a.N = n;
-        a.H = xd.H;
-        a.W = xd.W;
-        a.C = xd.C;
-        a.Ho = yd.H;
-        a.Wo = yd.W;
-        a.k = op.KH;
-        a.stride = op.stride;
-        a.pad_t = op.pad_t;
-        a.pad_l = op.pad_l;
-        a.zero_pad = op.zero_pad;
-        a.act2 = op.act2;
-        a.mode = op.pool_mode;
-        if (yd.parent >= 0) {
-          const TensorDesc& pd = tensors[yd.parent];
-          a.y_ld = pd.C;
-          a.y_coff = yd.coff;
-          a.y_H = pd.H;
-          a.y_W = pd.W;
-          a.y_oy = yd.oy;
-          a.y_ox = yd.ox;
-        } else {
-          a.y_ld = yd.C;
-          a.y_coff = 0;
-          a.y_H = yd.H;
-          a.y_W = yd.W;
-          a.y_oy = a.y_ox = 0;
-        }
-        if (maxpool_run(a, st)) return -1;
-        break;
-      }
-      case OP_DWFULL: {
-        const TensorDesc& xd = tensors[op.x];
-        if (dwfull_run(ptr(op.x), op.d_w, op.d_scale, op.d_shift, ptr(op.y), n, xd.H * xd.W, xd.C, st)) return -1;
-        break;
-      }
-      case OP_LRN: {
-        const TensorDesc& xd = tensors[op.x];
-        // tf.nn.lrn defaults: depth_radius 5, bias 1; alpha / beta from inceptionv3.py:95
-        if (lrn_run(ptr(op.x), ptr(op.y), (int64_t)n * xd.H * xd.W, xd.C, 5, 1.f, 1e-4f, 0.75f, st)) return -1;
-        break;
-      }
-      case OP_ZERO: {
-        const TensorDesc& yd = tensors[op.y];
-        DIF_HIP(hipMemsetAsync(ptr(op.y), 0, (size_t)n * yd.elems() * sizeof(float), st));
-        break;
-      }
-      case OP_L2NORM:
-        if (l2norm_run(ptr(op.x), ptr(op.y), n, op.Cout, 1e-12f, st)) return -1;
-        break;
+
+  const int nl = (int)lanes.size();
+  if (op_ms || nl == 1 || n < 64) {
+    std::vector<hipEvent_t> ev;
+    if (op_ms) {
+      ev.resize(ops.size() + 1);
+      for (auto& e : ev) DIF_HIP(hipEventCreate(&e));
+      DIF_HIP(hipEventRecord(ev[0], st));
     }
-    ++op_index;
-    if (op_ms) DIF_HIP(hipEventRecord(ev[op_index], st));
+    for (size_t i = 0; i < ops.size(); ++i) {
+      if (run_op(ops[i], lanes[0], xin, n, layout, dtype, out, st)) return -1;
+      if (op_ms) DIF_HIP(hipEventRecord(ev[i + 1], st));
+    }
+    if (op_ms) {
+      DIF_HIP(hipStreamSynchronize(st));
+      for (size_t i = 0; i < ops.size(); ++i) DIF_HIP(hipEventElapsedTime(&op_ms[i], ev[i], ev[i + 1]));
+      for (auto& e : ev) (void)hipEventDestroy(e);
+    }
+    return 0;
   }
-  if (op_ms) {
-    DIF_HIP(hipStreamSynchronize(st));
-    for (size_t i = 0; i < ops.size(); ++i) DIF_HIP(hipEventElapsedTime(&op_ms[i], ev[i], ev[i + 1]));
-    for (auto& e : ev) (void)hipEventDestroy(e);
+
+  const size_t in_bytes = (size_t)in_h * in_w * 3 * (dtype == DIF_DTYPE_U8 ? 1 : 4);
+  const int64_t out_elems = tensors[output_tensor].elems();
+  std::vector<int> start(nl + 1, 0);
+  for (int l = 0; l < nl; ++l) {
+    int c = n / nl + (l < n % nl ? 1 : 0);
+    if (l > 0 && c > lanes[l].cap) c = lanes[l].cap;     // cannot happen: cap = ceil(max_batch / nl)
+    start[l + 1] = start[l] + c;
+  }
+  DIF_HIP(hipEventRecord(ev_start, st));
+  for (int l = 1; l < nl; ++l) DIF_HIP(hipStreamWaitEvent(lanes[l].stream, ev_start, 0));
+  for (size_t i = 0; i < ops.size(); ++i) {
+    for (int l = 0; l < nl; ++l) {
+      const int c = start[l + 1] - start[l];
+      if (c == 0) continue;
+      hipStream_t ls = l == 0 ? st : lanes[l].stream;
+      if (run_op(ops[i], lanes[l], static_cast<const char*>(xin) + (size_t)start[l] * in_bytes, c, layout, dtype,
+                 out + (int64_t)start[l] * out_elems, ls))
+        return -1;
+    }
+  }
+  for (int l = 1; l < nl; ++l) {
+    DIF_HIP(hipEventRecord(lanes[l].done, lanes[l].stream));
+    DIF_HIP(hipStreamWaitEvent(st, lanes[l].done, 0));
   }
   return 0;
 }

@@ -85,18 +85,28 @@ struct Net {
   bool finalized = false;
   int max_batch = 0;
   std::vector<void*> allocs;
-  std::vector<float*> bufs;
+  // a lane = one in-flight slice of the batch: its own activation buffers, stream-K workspace
+  // and (beyond lane 0, which uses the caller's stream) its own HIP stream
+  struct Lane {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    int cap = 0;
+    std::vector<float*> bufs;
+    float* sk_slab = nullptr;
+    unsigned* sk_flag = nullptr;
+    unsigned sk_epoch = 0;
+  };
+  std::vector<Lane> lanes;
+  hipEvent_t ev_start = nullptr;
   std::vector<int64_t> buf_elems;   // per image
-  float* sk_slab = nullptr;         // stream-K workspace of the conv kernel
-  unsigned* sk_flag = nullptr;
   int sk_max_blocks = 0;
-  unsigned sk_epoch = 0;
   int sk_spin_limit = 1 << 18;
 
   ~Net();
   int build();                       // dispatch on arch/head
   int finalize(int max_batch);
   int embed(const void* x, int n, int layout, int dtype, float* out, hipStream_t st, float* op_ms = nullptr);
+  int run_op(const Op& op, Lane& L, const void* x, int n, int layout, int dtype, float* out, hipStream_t st);
   const char* kernel_name(const Op& op, int n) const;
   double flops_per_image() const;
   void release_device();
