@@ -23,7 +23,11 @@ def latest(pattern):
 def main():
     lines = []
     for w, forwards_ks in (('r50', 14), ('r100', 14)):
-        ks = latest('ks_%s/*/*_kernel_stats.csv' % w)
+        ks = latest('ks1_%s/*/*_kernel_stats.csv' % w)          # single-lane run: durations do not overlap
+        ks2 = latest('ks_%s/*/*_kernel_stats.csv' % w)          # default two-lane run
+        shutil.copy(ks2, os.path.join(PROF, '%s_%s_b256_kernel_stats_2lanes.csv' % (ROUND, w)))
+        shutil.copy(os.path.join(OUT, 'bench1_%s.json' % w), os.path.join(PROF, '%s_%s_b256_bench_1lane.json' % (ROUND, w)))
+        bench1 = json.load(open(os.path.join(OUT, 'bench1_%s.json' % w)))
         pf = latest('pf_%s/*/*_counter_collection.csv' % w)
         pw = latest('pw_%s/*/*_counter_collection.csv' % w)
         shutil.copy(ks, os.path.join(PROF, '%s_%s_b256_kernel_stats.csv' % (ROUND, w)))
@@ -38,11 +42,14 @@ def main():
                 conv_calls += int(r['Calls'])
         bench = json.load(open(os.path.join(OUT, 'bench_%s.json' % w)))
         traffic = json.load(open(os.path.join(PROF, '%s_%s_b256_hbm_traffic.json' % (ROUND, w))))['total']
-        lines.append('%-4s conv kernels: %d launches/forward, %.3f ms/forward under rocprofv3 (profiled run) | bench.py HIP events: '
-                     'forward %.3f ms, %.1f TFLOP/s, frac %.3f | %.0f faces/s | fabric traffic %.1f GB/forward'
-                     % (w, conv_calls // forwards_ks, conv_ns / forwards_ks / 1e6, bench['roofline']['forward_ms_hip_events'],
-                        bench['roofline']['achieved'], bench['roofline']['frac'], bench['value'],
-                        traffic['conv_hbm_bytes_per_forward'] / 1e9))
+        lines.append('%-4s ONE lane (DIF_STREAMS=1): %d conv launches/forward, sum of conv kernel durations %.3f ms/forward '
+                     '(rocprofv3 kernel-trace) vs HIP-event forward %.3f ms (%.1f TFLOP/s, frac %.3f)\n'
+                     '     TWO lanes (default): HIP-event forward %.3f ms, %.1f TFLOP/s, frac %.3f, %.0f faces/s incl. match | '
+                     'fabric traffic %.1f GB/forward'
+                     % (w, conv_calls // forwards_ks, conv_ns / forwards_ks / 1e6,
+                        bench1['roofline']['forward_ms_hip_events'], bench1['roofline']['achieved'], bench1['roofline']['frac'],
+                        bench['roofline']['forward_ms_hip_events'], bench['roofline']['achieved'], bench['roofline']['frac'],
+                        bench['value'], traffic['conv_hbm_bytes_per_forward'] / 1e9))
     print('\n'.join(lines))
     with open(os.path.join(PROF, '%s_summary.txt' % ROUND), 'w') as fh:
         fh.write('\n'.join(lines) + '\n')
