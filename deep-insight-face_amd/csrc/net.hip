@@ -143,9 +143,7 @@ int Net::conv(const std::string& name, int x, int KH, int KW, int stride, int pa
     Ho = (xd.H + 2 * pad - KH) / stride + 1;
     Wo = (xd.W + 2 * pad - KW) / stride + 1;
   }
-  if (wsuffix == "/kernel" && KH * KW * op.Cin_true > 0) {
-    // dense layers are registered by the caller with their own 2-D shape
-  }
+  // (dense layers re-register their kernel with its own 2-D [in, out] shape after this call)
   op.w = P(name + wsuffix, {KH, KW, op.Cin_true, Cout});
   if (bias) op.bias = P(name + "/bias", {Cout});
   op.bn = bn;
