@@ -83,6 +83,8 @@ def cpu_baseline(arch, head, gallery_rows, sample=96):
     t1 = time.perf_counter()
     od.match(e, gal, 1)
     t2 = time.perf_counter()
+    od.match_blas(e, gal, 1)                                  # the "fair" CPU variant: one sgemm + argmax
+    t3 = time.perf_counter()
     try:
         from threadpoolctl import threadpool_info
         cores = max([int(t.get('num_threads', 1)) for t in threadpool_info()] or [1])   # BLAS threads actually used
@@ -92,6 +94,9 @@ def cpu_baseline(arch, head, gallery_rows, sample=96):
         'value': sample / (t2 - t0), 'unit': 'faces/s', 'cores': cores, 'kind': 'port',
         'sample': '%d faces: oracle embed (NumPy/BLAS, %.2fs) + reference-formula match vs %d rows (%.2fs)'
                   % (sample, t1 - t0, gallery_rows, t2 - t1),
+        'embed_only_faces_per_s': sample / (t1 - t0),
+        'match_reference_formula_probes_per_s': sample / (t2 - t1),
+        'match_blas_sgemm_probes_per_s': sample / (t3 - t2),
     }
 
 
