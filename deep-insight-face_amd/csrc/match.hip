@@ -280,11 +280,14 @@ static int launch_match_tiles(const Gallery* g, const float* probes, int B, int 
 }
 
 static int match_tile_kind(int B) {
-  // 0: 128 gallery rows x 128 probes, 1: 128 x 64, 3: 64 x 64
+  // 0: 128 gallery rows x 128 probes, 1: 128 x 64, 3: 64 x 64, 4: 128 x 32 (four waves stacked on M)
   static const int forced = getenv("DIF_MATCH_TILE") ? atoi(getenv("DIF_MATCH_TILE")) : -1;
   if (forced >= 0) return forced;
   // unlike the convolutions, the 128-row tiles win here (the arg-min epilogue and the probe
   // re-reads weigh more on small tiles: 117 vs 99 TF at 256 x 1M, 128 vs 120 TF at 4096 x 125k)
+  // B <= 32: the 32-probe tile halves the padded MFMA work, which at 1M rows would otherwise
+  // (67 GFLOP for 64 padded probes) cost more than streaming the gallery from HBM
+  if (B <= 32) return 4;
   return B <= 64 ? 1 : 0;
 }
 
@@ -292,7 +295,7 @@ int match_plan_parts(const Gallery* g, int B) {
   // One gallery tile per block while the partial buffer stays small; beyond that the blocks
   // stride over tiles (the imbalance of a long stride is negligible).
   const int kind = match_tile_kind(B);
-  const int BM = kind == 3 ? 64 : 128;
+  const int BM = kind == 3 ? 64 : 128;   // kinds 0, 1 and 4 all take 128 gallery rows per tile
   const int64_t gtiles = (g->n + BM - 1) / BM;
   int64_t cap = (int64_t)(32 << 20) / ((int64_t)B * 8);   // <= 32 MiB of (key, idx) partials
   if (cap < 1024) cap = 1024;
@@ -321,6 +324,8 @@ int match_run(Gallery* g, const float* probes, int B, int metric, int64_t* idx_o
   const int kind = match_tile_kind(B);
   if (kind == 3)
     rc = launch_match_tiles<Tile<1, 1>>(g, probes, B, metric, nparts, st);
+  else if (kind == 4 && B <= 32)
+    rc = launch_match_tiles<Tile<1, 1, 4, 1>>(g, probes, B, metric, nparts, st);
   else if (kind == 1 || B <= 64)
     rc = launch_match_tiles<Tile<2, 1>>(g, probes, B, metric, nparts, st);
   else
