@@ -183,3 +183,25 @@ def test_streamk_fallback_branch(cuda, monkeypatch):
     assert cosine_gap(got, normal).max() < 1e-6
     model.close()
     ref_model.close()
+
+
+def test_embed_full_batch_properties(cuda):
+    """BASELINE config-2 batch (256 crops, ResNet50V2+GDC 512-d) without the oracle: outputs are
+    unit-norm and finite, rows equal the same crops embedded in a small batch (up to float32
+    rounding), a permuted batch gives permuted embeddings, and 8 spot rows match the oracle."""
+    model, p = build('resnet', 'v2', 512, max_batch=256)
+    u8 = crops_u8(256, seed=42)
+    model.set_input_transform(scale=1 / 255.)
+    full = model.predict_on_batch(u8)
+    assert full.shape == (256, 512) and np.all(np.isfinite(full))
+    np.testing.assert_allclose(np.linalg.norm(full, axis=1), 1.0, atol=1e-5)
+    small = model.predict_on_batch(u8[100:108])
+    assert cosine_gap(small, full[100:108]).max() < 1e-6
+    perm = np.random.default_rng(0).permutation(256)
+    permuted = model.predict_on_batch(u8[perm])
+    assert cosine_gap(permuted, full[perm]).max() < 1e-6
+    model.set_input_transform()
+    rows = [0, 31, 64, 127, 128, 200, 254, 255]
+    want = nets.embed(scaled(u8[rows]), p, 'resnet', 512, 'v2')
+    assert cosine_gap(full[rows], want).max() < TOL
+    model.close()
