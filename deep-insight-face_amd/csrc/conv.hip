@@ -578,12 +578,12 @@ static int launch_conv_pre(const ConvArgs& a, hipStream_t st) {
   // Resident blocks for this tile shape (LDS-limited: 2 per CU, 4 for the 64x64 tile).
   int64_t slots = (T::LDS_BYTES * 4 <= 160 * 1024 ? 4 : 2) * (int64_t)num_cus();
   if (slots > a.sk_max_blocks) slots = a.sk_max_blocks;
-  // Many tiles, or a short K loop (< 33 steps: a split tile's slab hand-off would cost more
+  // Many tiles, or a short K loop (< 32 steps: a split tile's slab hand-off would cost more
   // than the imbalance it removes -- measured): one whole tile per block, the hardware
   // dispatcher balances them and no tile is ever split.  Few long tiles: stream-K, one equal
   // K-step range per resident block.
   int64_t P;
-  static const int sk_min_ks = getenv("DIF_SK_MIN_KS") ? atoi(getenv("DIF_SK_MIN_KS")) : 33;
+  static const int sk_min_ks = getenv("DIF_SK_MIN_KS") ? atoi(getenv("DIF_SK_MIN_KS")) : 32;
   if (tiles >= 8 * slots || KS < sk_min_ks) {
     P = tiles;
   } else {
