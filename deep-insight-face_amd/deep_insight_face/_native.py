@@ -32,6 +32,10 @@ SIGNATURES = {
     'dif_device_count': (c_int, []),
     'dif_pairwise': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     'dif_threshold_counts': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'dif_yolo_decode': (c_int, [P(c_void_p), P(ctypes.c_int32), P(c_float), c_int, c_int, c_int, c_int, c_int,
+                                c_void_p, c_void_p, c_void_p, c_void_p]),
+    'dif_nms': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p,
+                        c_void_p, c_void_p]),
     'dif_gallery_create': (c_int, [P(c_void_p), c_int]),
     'dif_gallery_destroy': (c_int, [c_void_p]),
     'dif_gallery_set': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),

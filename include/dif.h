@@ -64,6 +64,25 @@ int dif_threshold_counts(const float* dist_dev, const uint8_t* issame_dev, const
                          const double* thresholds_dev, int n_thresholds, int n_folds, int32_t* counts_dev,
                          void* stream);
 
+/* ------------------------------------------------------------------ detector post-processing
+ * YOLOv3-face box decode and suppression (detector/yolov3.py:36-172).
+ * dif_yolo_decode: feats_dev = HOST array of n_layers DEVICE pointers, coarse grid first, each
+ * [n_images][gh][gw][3*(5+n_classes)]; grid_hw_host [n_layers][2]; anchors_host [n_layers][3][2]
+ * (pixels of the network input, already selected per layer); image_shape_dev [n_images][2] =
+ * original (height, width).  Writes boxes_dev [n_images][n_boxes][4] (y_min, x_min, y_max, x_max in
+ * image pixels; n_boxes = sum gh*gw*3) and scores_dev [n_images][n_boxes][n_classes] =
+ * confidence * class probability (yolo_head :36-66, correct_boxes :69-93, boxes_and_scores :96-106).
+ * dif_nms: per (image, class) keep boxes with score >= score_threshold and run the greedy
+ * suppression of tf.image.non_max_suppression (get_yolo_output :149-160): keep_idx_dev
+ * [n_images][n_classes][max_boxes] (box indices in pick order, -1 padded), keep_count_dev
+ * [n_images][n_classes]; alive_ws_dev = n_images*n_classes*n_boxes bytes of scratch. */
+int dif_yolo_decode(const float* const* feats_dev, const int32_t* grid_hw_host, const float* anchors_host,
+                    int n_layers, int n_images, int n_classes, int input_h, int input_w,
+                    const float* image_shape_dev, float* boxes_dev, float* scores_dev, void* stream);
+int dif_nms(const float* boxes_dev, const float* scores_dev, int n_images, int n_boxes, int n_classes, int max_boxes,
+            float score_threshold, float iou_threshold, uint8_t* alive_ws_dev, int32_t* keep_idx_dev,
+            int32_t* keep_count_dev, void* stream);
+
 /* ------------------------------------------------------------------ gallery + 1:N match
  * The reference has no 1:N entry point; the semantics are utility.distance broadcast
  * over gallery rows + np.argmin (first minimum).  Housed Python-side under
