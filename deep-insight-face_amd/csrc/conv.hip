@@ -389,8 +389,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
           a.fd_wo.divmod(rr, ho, wo);
           o = (((int64_t)img * a.y_H + ho + a.y_oy) * a.y_W + wo + a.y_ox) * a.y_ld + a.y_coff + c;
         }
-        if (a.y) *reinterpret_cast<f32x4*>(a.y + o) = v;
-        if (a.y2) *reinterpret_cast<f32x4*>(a.y2 + o) = v2;
+        if (a.Cout % 4 == 0) {
+          if (a.y) *reinterpret_cast<f32x4*>(a.y + o) = v;
+          if (a.y2) *reinterpret_cast<f32x4*>(a.y2 + o) = v2;
+        } else {
+          // narrow heads whose channel count is not a multiple of 4 (e.g. 18 = 3*(5+1) YOLO
+          // outputs): rows are not 16-byte aligned, store the valid channels one by one
+          for (int j = 0; j < 4; ++j)
+            if (c + j < a.Cout) {
+              if (a.y) a.y[o + j] = v[j];
+              if (a.y2) a.y2[o + j] = v2[j];
+            }
+        }
       }
     }
   }
@@ -625,8 +635,11 @@ int conv_tile_choice(int64_t M, int Cout, int Kpad) {
 int conv_run(const ConvArgs& a, int tile, hipStream_t st) {
   if (a.M <= 0) return 0;
   if (a.Cin % 4 != 0) return set_error("conv: Cin must be a multiple of 4 (got %d)", a.Cin);
-  if (a.Cout % 4 != 0) return set_error("conv: Cout must be a multiple of 4 (got %d)", a.Cout);
-  if (a.y_ld % 4 != 0 || a.y_coff % 4 != 0) return set_error("conv: output view must be 16-byte aligned");
+  if (a.Cout % 4 != 0) {
+    if (a.res) return set_error("conv: a shortcut needs Cout %% 4 == 0 (got %d)", a.Cout);
+  } else if (a.y_ld % 4 != 0 || a.y_coff % 4 != 0) {
+    return set_error("conv: output view must be 16-byte aligned");
+  }
   if (a.y_ld < a.y_coff + a.Cout || a.y_H < a.Ho + a.y_oy || a.y_W < a.Wo + a.y_ox)
     return set_error("conv: output view does not fit its parent tensor");
   if (a.Kpad % BK != 0) return set_error("conv: Kpad must be a multiple of %d", BK);

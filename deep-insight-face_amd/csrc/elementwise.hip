@@ -129,6 +129,56 @@ int maxpool_run(const PoolArgs& a, hipStream_t st) {
   return 0;
 }
 
+// ---------------------------------------------------------------- upsample x2 / copy into a concat slice
+__global__ __launch_bounds__(256) void upsample2_kernel(const float* __restrict__ x, float* __restrict__ y, int N,
+                                                        int H, int W, int C, int y_ld, int y_coff) {
+  const int C4 = C / 4;
+  const int64_t total = (int64_t)N * (2 * H) * (2 * W) * C4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
+    int64_t p = i / C4;
+    const int wo = (int)(p % (2 * W));
+    p /= 2 * W;
+    const int ho = (int)(p % (2 * H));
+    const int64_t n = p / (2 * H);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((n * H + ho / 2) * W + wo / 2) * C + c4 * 4);
+    *reinterpret_cast<f32x4*>(y + ((n * 2 * H + ho) * (2 * W) + wo) * (int64_t)y_ld + y_coff + c4 * 4) = v;
+  }
+}
+
+int upsample2_run(const float* x, float* y, int N, int H, int W, int C, int y_ld, int y_coff, hipStream_t st) {
+  if (C % 4 != 0 || y_ld % 4 != 0 || y_coff % 4 != 0) return set_error("upsample: channels must be 16-byte aligned");
+  const int64_t total = (int64_t)N * 4 * H * W * (C / 4);
+  if (total == 0) return 0;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(upsample2_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, y, N, H, W, C, y_ld, y_coff);
+  DIF_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void copy_to_view_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           int64_t npix, int C, int y_ld, int y_coff) {
+  const int C4 = C / 4;
+  const int64_t total = npix * C4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
+    const int64_t p = i / C4;
+    *reinterpret_cast<f32x4*>(y + p * y_ld + y_coff + c4 * 4) = *reinterpret_cast<const f32x4*>(x + p * C + c4 * 4);
+  }
+}
+
+int copy_to_view_run(const float* x, float* y, int64_t npix, int C, int y_ld, int y_coff, hipStream_t st) {
+  if (C % 4 != 0 || y_ld % 4 != 0 || y_coff % 4 != 0) return set_error("copy: channels must be 16-byte aligned");
+  const int64_t total = npix * (C / 4);
+  if (total == 0) return 0;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(copy_to_view_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, y, npix, C, y_ld, y_coff);
+  DIF_HIP(hipGetLastError());
+  return 0;
+}
+
 // ---------------------------------------------------------------- local response normalisation
 // tf.nn.lrn(x, alpha=1e-4, beta=0.75) (networks/inceptionv3.py:95): depth_radius 5, bias 1.
 __global__ __launch_bounds__(256) void lrn_kernel(const float* __restrict__ x, float* __restrict__ y,

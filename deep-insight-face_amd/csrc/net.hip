@@ -122,7 +122,7 @@ int Net::pool(const std::string& name, int x, int k, int stride, int pad, int mo
 // kernel at stride 1 (pad 0 before, k-1 after).  Returns the y tensor (or -1 if !want_y).
 int Net::conv(const std::string& name, int x, int KH, int KW, int stride, int pad, int Cout, bool bias,
               const BNRef& bn, int act, int alpha, int res, int res_stride, bool want_y, const BNRef& bn2,
-              int act2, int* y2_out, const std::string& wsuffix, bool same_pad_even) {
+              int act2, int* y2_out, const std::string& wsuffix, bool same_pad_even, int pad_br) {
   const TensorDesc xd = tensors[x];
   Op op;
   op.kind = OP_CONV;
@@ -140,8 +140,9 @@ int Net::conv(const std::string& name, int x, int KH, int KW, int stride, int pa
     Ho = xd.H;
     Wo = xd.W;
   } else {
-    Ho = (xd.H + 2 * pad - KH) / stride + 1;
-    Wo = (xd.W + 2 * pad - KW) / stride + 1;
+    const int pb = pad_br < 0 ? pad : pad_br;      // bottom/right padding (darknet pads top/left only at stride 2)
+    Ho = (xd.H + pad + pb - KH) / stride + 1;
+    Wo = (xd.W + pad + pb - KW) / stride + 1;
   }
   // (dense layers re-register their kernel with its own 2-D [in, out] shape after this call)
   op.w = P(name + wsuffix, {KH, KW, op.Cin_true, Cout});
@@ -544,6 +545,104 @@ int Net::build_nn4() {
   return 0;
 }
 
+// ----------------------------------------------------------------------------- YOLOv3-face detector
+// The network the reference loads as a converted Keras model (detector/run.py:140; converter
+// scripts/yolo_convert_tf.py:60-215 over detector/yolo_cfg/yolov3-face.cfg): Darknet-53
+// (residual stages of 1, 2, 8, 8, 4 blocks) + three detection heads, one class -> 18 = 3*(5+1)
+// channels per head.  Layer semantics as the converter builds them: Conv2D (stride 1: 'same';
+// stride 2: ZeroPadding2D(((1,0),(1,0))) + 'valid') without bias -> BatchNormalization (Keras
+// default epsilon 1e-3) -> LeakyReLU(0.1); the three head outputs are linear convolutions with
+// bias; shortcut = Add; route = pass-through or channel concatenation; upsample = nearest x2.
+// Parameters are named conv_<i> / bn_<i> with i = the convolution's ordinal in the cfg (0..74).
+int Net::build_yolov3() {
+  const BNRef none;
+  if (in_h % 32 != 0 || in_w % 32 != 0) return set_error("yolov3 input must be a multiple of 32 (got %dx%d)", in_h, in_w);
+  const int n_out = 3 * (5 + (emd > 0 ? emd : 1));   // emd_size carries the class count for this arch
+  input_tensor = T(in_h, in_w, 4);
+  {
+    Op in;
+    in.kind = OP_INPUT;
+    in.name = "input";
+    in.y = input_tensor;
+    ops.push_back(in);
+  }
+  int ci = 0;
+  // conv + BN + leaky; res >= 0 adds a shortcut after the activation (Add([from, conv]))
+  auto cbl = [&](int x, int cout, int k, int stride, int res) {
+    char nm[32], bm[32];
+    snprintf(nm, sizeof(nm), "conv_%d", ci);
+    snprintf(bm, sizeof(bm), "bn_%d", ci);
+    ++ci;
+    const BNRef bn = BN(bm, cout, EPS_KERAS);
+    const int pad = (k == 3) ? 1 : 0;
+    const int y = conv(nm, x, k, k, stride, pad, cout, false, bn, ACT_PRELU, -1, res, 1, true, none, ACT_NONE, nullptr,
+                       "/kernel", false, stride == 2 ? 0 : -1);
+    ops.back().const_alpha = 0.1f;
+    return y;
+  };
+  auto linear = [&](int x, int cout) {
+    char nm[32];
+    snprintf(nm, sizeof(nm), "conv_%d", ci);
+    ++ci;
+    return conv(nm, x, 1, 1, 1, 0, cout, true, none, ACT_NONE, -1, -1, 1, true, none, ACT_NONE, nullptr);
+  };
+  auto stage = [&](int x, int cout, int blocks) {
+    x = cbl(x, cout, 3, 2, -1);                       // downsample
+    for (int b = 0; b < blocks; ++b) {
+      const int t = cbl(x, cout / 2, 1, 1, -1);
+      x = cbl(t, cout, 3, 1, x);                      // + shortcut
+    }
+    return x;
+  };
+  int x = cbl(input_tensor, 32, 3, 1, -1);
+  x = stage(x, 64, 1);
+  x = stage(x, 128, 2);
+  const int r36 = x = stage(x, 256, 8);               // cfg layer 36
+  const int r61 = x = stage(x, 512, 8);               // cfg layer 61
+  x = stage(x, 1024, 4);
+  // head: five alternating 1x1 / 3x3 convs, then 3x3 + linear 1x1 detection conv
+  auto head = [&](int x, int c, int* branch) {
+    x = cbl(x, c, 1, 1, -1);
+    x = cbl(x, 2 * c, 3, 1, -1);
+    x = cbl(x, c, 1, 1, -1);
+    x = cbl(x, 2 * c, 3, 1, -1);
+    x = cbl(x, c, 1, 1, -1);
+    *branch = x;                                      // route -4
+    x = cbl(x, 2 * c, 3, 1, -1);
+    return linear(x, n_out);
+  };
+  auto up_concat = [&](int x, int c, int skip) {
+    x = cbl(x, c, 1, 1, -1);
+    const TensorDesc xd = tensors[x];
+    const TensorDesc sd = tensors[skip];
+    const int cat = T(2 * xd.H, 2 * xd.W, xd.C + sd.C);
+    Op u;
+    u.kind = OP_UPSAMPLE;
+    u.name = "upsample";
+    u.x = x;
+    u.Cin = u.Cout = xd.C;
+    u.y = V(cat, 2 * xd.H, 2 * xd.W, xd.C, 0, 0, 0);
+    ops.push_back(u);
+    Op c2;
+    c2.kind = OP_COPY;
+    c2.name = "route_concat";
+    c2.x = skip;
+    c2.Cin = c2.Cout = sd.C;
+    c2.y = V(cat, sd.H, sd.W, sd.C, xd.C, 0, 0);
+    ops.push_back(c2);
+    return cat;
+  };
+  int br = -1;
+  const int y13 = head(x, 512, &br);
+  x = up_concat(br, 256, r61);
+  const int y26 = head(x, 256, &br);
+  x = up_concat(br, 128, r36);
+  const int y52 = head(x, 128, &br);
+  output_tensor = y13;
+  extra_outputs = {y26, y52};
+  return 0;
+}
+
 int Net::build() {
   if (emd <= 0) return set_error("emd_size must be positive");
   if (in_h < 32 || in_w < 32) return set_error("input must be at least 32x32");
@@ -553,13 +652,14 @@ int Net::build() {
     return build_iresnet(l);
   }
   if (arch == "nn4") return build_nn4();
+  if (arch == "yolov3") return build_yolov3();
   if (arch == "iresnet100") {
     static const int l[4] = {3, 13, 30, 3};
     return build_iresnet(l);
   }
   // the reference asserts net in ('mobilenet','resnet','vgg16') (triplet.py:77); only the
   // ResNet path is on the hot path named by north_star
-  return set_error("Invalid bottleneck network '%s' (supported: resnet, iresnet50, iresnet100, nn4)", arch.c_str());
+  return set_error("Invalid bottleneck network '%s' (supported: resnet, iresnet50, iresnet100, nn4, yolov3)", arch.c_str());
 }
 
 double Net::flops_per_image() const {
@@ -571,7 +671,9 @@ double Net::flops_per_image() const {
 // ----------------------------------------------------------------------------- finalize
 static int upload(Net* net, const std::vector<float>& host, float** out) {
   float* d = nullptr;
-  DIF_HIP(hipMalloc(&d, std::max<size_t>(host.size(), 1) * sizeof(float)));
+  // +4 floats: per-channel vectors are read 16 bytes at a time, also when Cout % 4 != 0
+  DIF_HIP(hipMalloc(&d, (host.size() + 4) * sizeof(float)));
+  DIF_HIP(hipMemset(d, 0, (host.size() + 4) * sizeof(float)));
   net->allocs.push_back(d);
   if (!host.empty()) DIF_HIP(hipMemcpy(d, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
   *out = d;
@@ -634,6 +736,9 @@ int Net::finalize(int mb) {
       if (!scale.empty() && upload(this, scale, &op.d_scale)) return -1;
       if (!shift.empty() && upload(this, shift, &op.d_shift)) return -1;
       if (op.alpha >= 0 && upload(this, params[op.alpha].data, &op.d_alpha)) return -1;
+      if (op.alpha < 0 && op.const_alpha != 0.f &&
+          upload(this, std::vector<float>((size_t)op.Cout, op.const_alpha), &op.d_alpha))
+        return -1;
     } else if (op.kind == OP_DWFULL) {
       if (upload(this, params[op.w].data, &op.d_w)) return -1;   // [H][W][C][1] == [HW][C]
       fold(this, op.bn, -1, op.Cout, &scale, &shift);
@@ -665,12 +770,13 @@ int Net::finalize(int mb) {
       if (t >= 0) tensors[t].last_use = std::max(tensors[t].last_use, i);
   }
   tensors[output_tensor].last_use = (int)ops.size();   // written straight into the caller's buffer
+  for (int e : extra_outputs) tensors[e].last_use = (int)ops.size();
   buf_elems.clear();
   std::vector<int> free_list;
   for (int i = 0; i < (int)ops.size(); ++i) {
     const Op& op = ops[i];
     for (int t : {R(op.y), R(op.y2)}) {
-      if (t < 0 || t == output_tensor || tensors[t].buf >= 0) continue;
+      if (t < 0 || is_output(t) || tensors[t].buf >= 0) continue;
       const int64_t need = tensors[t].elems();
       int best = -1;
       for (int k = 0; k < (int)free_list.size(); ++k) {
@@ -686,7 +792,7 @@ int Net::finalize(int mb) {
       }
     }
     for (int t : {R(op.x), R(op.res), R(op.y), R(op.y2)})
-      if (t >= 0 && t != output_tensor && tensors[t].last_use == i && tensors[t].buf >= 0) {
+      if (t >= 0 && !is_output(t) && tensors[t].last_use == i && tensors[t].buf >= 0) {
         if (std::find(free_list.begin(), free_list.end(), tensors[t].buf) == free_list.end())
           free_list.push_back(tensors[t].buf);
       }
@@ -696,7 +802,7 @@ int Net::finalize(int mb) {
   int nl = getenv("DIF_STREAMS") ? atoi(getenv("DIF_STREAMS")) : 2;
   if (nl < 1) nl = 1;
   if (nl > 8) nl = 8;
-  if (max_batch < 64 * nl) nl = 1;
+  if (max_batch < 64 * nl || !extra_outputs.empty()) nl = 1;
   lanes.assign(nl, Lane());
   DIF_HIP(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
   for (int l = 0; l < nl; ++l) {
@@ -736,6 +842,8 @@ const char* Net::kernel_name(const Op& op, int n) const {
     case OP_L2NORM: return "l2norm_kernel";
     case OP_LRN: return "lrn_kernel";
     case OP_ZERO: return "memset";
+    case OP_UPSAMPLE: return "upsample2_kernel";
+    case OP_COPY: return "copy_to_view_kernel";
     case OP_CONV: {
       const TensorDesc& yd = tensors[op.y >= 0 ? op.y : op.y2];
       static const char* names[4] = {"conv_igemm_kernel<128x128>", "conv_igemm_kernel<128x64>",
@@ -750,7 +858,7 @@ const char* Net::kernel_name(const Op& op, int n) const {
 int Net::run_op(const Op& op, Lane& L, const void* xin, int n, int layout, int dtype, float* out, hipStream_t st) {
   auto ptr = [&](int t) -> float* {
     if (t < 0) return nullptr;
-    if (t == output_tensor) return out;
+    if (is_output(t)) return out + (int64_t)n * output_offset(t);   // outputs are laid out one after another
     return L.bufs[tensors[root_of(t)].buf];
   };
   switch (op.kind) {
@@ -894,6 +1002,20 @@ int Net::run_op(const Op& op, Lane& L, const void* xin, int n, int layout, int d
       if (lrn_run(ptr(op.x), ptr(op.y), (int64_t)n * xd.H * xd.W, xd.C, 5, 1.f, 1e-4f, 0.75f, st)) return -1;
       break;
     }
+    case OP_UPSAMPLE: {
+      const TensorDesc& xd = tensors[op.x];
+      const TensorDesc& yd = tensors[op.y];
+      const int ld = yd.parent >= 0 ? tensors[yd.parent].C : yd.C;
+      if (upsample2_run(ptr(op.x), ptr(op.y), n, xd.H, xd.W, xd.C, ld, yd.coff, st)) return -1;
+      break;
+    }
+    case OP_COPY: {
+      const TensorDesc& xd = tensors[op.x];
+      const TensorDesc& yd = tensors[op.y];
+      const int ld = yd.parent >= 0 ? tensors[yd.parent].C : yd.C;
+      if (copy_to_view_run(ptr(op.x), ptr(op.y), (int64_t)n * xd.H * xd.W, xd.C, ld, yd.coff, st)) return -1;
+      break;
+    }
     case OP_ZERO: {
       const TensorDesc& yd = tensors[op.y];
       DIF_HIP(hipMemsetAsync(ptr(op.y), 0, (size_t)n * yd.elems() * sizeof(float), st));
@@ -940,7 +1062,7 @@ int Net::embed(const void* xin, int n, int layout, int dtype, float* out, hipStr
   }
 
   const size_t in_bytes = (size_t)in_h * in_w * 3 * (dtype == DIF_DTYPE_U8 ? 1 : 4);
-  const int64_t out_elems = tensors[output_tensor].elems();
+  const int64_t out_elems = tensors[output_tensor].elems();   // (multi-output nets never take this path)
   std::vector<int> start(nl + 1, 0);
   for (int l = 0; l < nl; ++l) {
     int c = n / nl + (l < n % nl ? 1 : 0);

@@ -1,6 +1,7 @@
 // Embedding network: a static list of layer ops over pooled NHWC activation buffers,
 // executed as a fixed sequence of kernel launches on the caller's stream.
 #pragma once
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -36,7 +37,7 @@ struct TensorDesc {
   int64_t elems() const { return (int64_t)H * W * C; }
 };
 
-enum OpKind { OP_INPUT, OP_CONV, OP_MAXPOOL, OP_DWFULL, OP_L2NORM, OP_LRN, OP_ZERO };
+enum OpKind { OP_INPUT, OP_CONV, OP_MAXPOOL, OP_DWFULL, OP_L2NORM, OP_LRN, OP_ZERO, OP_UPSAMPLE, OP_COPY };
 
 struct Op {
   OpKind kind = OP_CONV;
@@ -48,6 +49,7 @@ struct Op {
   int res_stride = 1;
   int zero_pad = 0;
   int pool_mode = POOL_MAX;
+  float const_alpha = 0.f;    // act == ACT_PRELU with one slope for every channel (LeakyReLU)
   bool chw_flatten = false;
   int k_order = 0;            // see ConvArgs::k_order   // dense after an NCHW-order flatten: permute kernel rows at pack time
   // parameters
@@ -78,6 +80,20 @@ struct Net {
   std::vector<TensorDesc> tensors;
   std::vector<Op> ops;
   int input_tensor = -1, output_tensor = -1;
+  std::vector<int> extra_outputs;   // further outputs after output_tensor (detector heads)
+  bool is_output(int t) const {
+    return t == output_tensor || std::find(extra_outputs.begin(), extra_outputs.end(), t) != extra_outputs.end();
+  }
+  int64_t output_offset(int t) const {   // floats per image that precede output t in the caller's buffer
+    if (t == output_tensor) return 0;
+    int64_t off = tensors[output_tensor].elems();
+    for (int e : extra_outputs) {
+      if (e == t) return off;
+      off += tensors[e].elems();
+    }
+    return off;
+  }
+  int64_t output_elems() const { return output_offset(-2); }
   float in_scale = 1.f;
   float in_bias[3] = {0.f, 0.f, 0.f};
   int bgr = 0;
@@ -123,7 +139,8 @@ struct Net {
   int root_of(int t) const { return tensors[t].parent >= 0 ? tensors[t].parent : t; }
   int conv(const std::string& name, int x, int KH, int KW, int stride, int pad, int Cout, bool bias,
            const BNRef& bn, int act, int alpha, int res, int res_stride, bool want_y, const BNRef& bn2, int act2,
-           int* y2_out, const std::string& wsuffix = "/kernel", bool same_pad_even = false);
+           int* y2_out, const std::string& wsuffix = "/kernel", bool same_pad_even = false, int pad_br = -1);
+  int build_yolov3();
   int build_resnet50v2();
   int build_iresnet(const int* layers);
   int build_nn4();

@@ -99,6 +99,17 @@ int dif_net_output_dim(const dif_net* h, int64_t shape[3]) {
   return 0;
 }
 
+int dif_net_output_count(const dif_net* h) { return h ? 1 + (int)h->net.extra_outputs.size() : 0; }
+
+int dif_net_output_info(const dif_net* h, int i, int64_t shape[3]) {
+  if (!h || !shape || i < 0 || i > (int)h->net.extra_outputs.size()) return set_error("dif_net_output_info: bad index");
+  const TensorDesc& t = h->net.tensors[i == 0 ? h->net.output_tensor : h->net.extra_outputs[i - 1]];
+  shape[0] = t.C;
+  shape[1] = t.H;
+  shape[2] = t.W;
+  return 0;
+}
+
 int dif_net_embed(dif_net* h, const void* x_dev, int n, int layout, int dtype, float* out_dev, void* stream) {
   if (!h) return set_error("dif_net_embed: null handle");
   return h->net.embed(x_dev, n, layout, dtype, out_dev, (hipStream_t)stream);

@@ -99,6 +99,10 @@ struct PoolArgs {
   int y_ld, y_coff, y_H, y_W, y_oy, y_ox;
 };
 int maxpool_run(const PoolArgs& a, hipStream_t st);
+// nearest-neighbour x2 upsampling (keras UpSampling2D(2)) into an output view
+int upsample2_run(const float* x, float* y, int N, int H, int W, int C, int y_ld, int y_coff, hipStream_t st);
+// dense [N,H,W,C] -> channel slice of a wider tensor (concatenate with an earlier layer)
+int copy_to_view_run(const float* x, float* y, int64_t npix, int C, int y_ld, int y_coff, hipStream_t st);
 // tf.nn.lrn over the channel axis: y = x / (bias + alpha * sum_{|j-c|<=radius} x_j^2)^beta
 int lrn_run(const float* x, float* y, int64_t npix, int C, int radius, float bias, float alpha, float beta,
             hipStream_t st);

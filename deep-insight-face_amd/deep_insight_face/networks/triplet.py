@@ -35,6 +35,11 @@ class DifEmbedder:
         N.check(N.lib.dif_net_output_dim(self._h, shp))
         c, h, w = int(shp[0]), int(shp[1]), int(shp[2])
         self.output_shape = (c,) if (h == 1 and w == 1) else (h, w, c)
+        # networks with several outputs (the detector): one (h, w, c) per output
+        self.output_shapes = []
+        for i in range(N.lib.dif_net_output_count(self._h)):
+            N.check(N.lib.dif_net_output_info(self._h, i, shp))
+            self.output_shapes.append((int(shp[1]), int(shp[2]), int(shp[0])))
 
     # ---- parameters -----------------------------------------------------------------
     def param_spec(self):
@@ -124,6 +129,8 @@ class DifEmbedder:
             t = t.to(torch.float32)
         t = t.to(dev).contiguous()
         n = t.shape[0]
+        if len(self.output_shapes) > 1:
+            return self._embed_multi(t, n, layout, dtype, dev)
         out = torch.empty((n,) + self.output_shape, dtype=torch.float32, device=dev)
         per = int(np.prod(self.output_shape))
         flat = out.view(n, per)
@@ -132,6 +139,21 @@ class DifEmbedder:
             N.check(N.lib.dif_net_embed(self._h, N.ptr(t[s:e]), e - s, layout, dtype, N.ptr(flat[s:e]),
                                         N.stream_ptr()))
         return out
+
+    def _embed_multi(self, t, n, layout, dtype, dev):
+        """Several outputs: the library writes output 0 for the whole chunk, then output 1, ..."""
+        sizes = [int(np.prod(s)) for s in self.output_shapes]
+        outs = [torch.empty((n,) + s, dtype=torch.float32, device=dev) for s in self.output_shapes]
+        for s0 in range(0, n, self.max_batch):
+            e = min(n, s0 + self.max_batch)
+            c = e - s0
+            flat = torch.empty((c * sum(sizes),), dtype=torch.float32, device=dev)
+            N.check(N.lib.dif_net_embed(self._h, N.ptr(t[s0:e]), c, layout, dtype, N.ptr(flat), N.stream_ptr()))
+            off = 0
+            for o, sz, shp in zip(outs, sizes, self.output_shapes):
+                o[s0:e] = flat[off:off + c * sz].view((c,) + shp)
+                off += c * sz
+        return outs
 
     def profile(self, x):
         """Per-launch milliseconds of one forward of a CUDA uint8/float batch (diagnostic):
@@ -158,6 +180,8 @@ class DifEmbedder:
     def predict_on_batch(self, x):
         """NumPy in -> NumPy float32 out (Keras semantics); torch in -> CUDA tensor out."""
         out = self.embed(x)
+        if isinstance(out, list):
+            return out if torch.is_tensor(x) else [o.cpu().numpy() for o in out]
         return out if torch.is_tensor(x) else out.cpu().numpy()
 
     __call__ = predict_on_batch

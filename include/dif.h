@@ -127,6 +127,10 @@ int dif_net_set_input_transform(dif_net* net, float scale, const float bias[3], 
 /* pack weights for the kernels, upload, and size the activation workspace */
 int dif_net_finalize(dif_net* net, int max_batch);
 int dif_net_output_dim(const dif_net* net, int64_t shape[3]); /* {emd,1,1} or {C,H,W} for v3 */
+/* networks with several outputs (arch "yolov3": the three detection maps, coarse first; emd_size
+ * carries the class count): out_dev then holds output 0 for all n images, then output 1, ... */
+int dif_net_output_count(const dif_net* net);
+int dif_net_output_info(const dif_net* net, int i, int64_t shape[3]); /* {C,H,W} of output i */
 /* forward n <= max_batch images; x_dev is [n,H,W,3] (NHWC) or [n,3,H,W] (NCHW), f32 or u8;
  * out_dev is [n][emd] float32 (v3: [n,H,W,C] NHWC). */
 int dif_net_embed(dif_net* net, const void* x_dev, int n, int layout, int dtype, float* out_dev, void* stream);

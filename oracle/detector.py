@@ -107,3 +107,89 @@ def get_yolo_output(outputs, anchors, num_classes, image_shape, max_boxes=20, sc
         scores_.append(cs[keep])
         classes_.append(np.full(len(keep), c, dtype=np.int32))
     return np.concatenate(boxes_, axis=0), np.concatenate(scores_, axis=0), np.concatenate(classes_, axis=0)
+
+
+# --------------------------------------------------------------------------- YOLOv3-face network
+# The detector network itself is not defined in Python in the reference: it is the Darknet cfg
+# detector/yolo_cfg/yolov3-face.cfg turned into a Keras model by scripts/yolo_convert_tf.py:60-215.
+# Restated here from that converter's layer semantics (Conv2D without bias -> BatchNormalization
+# (Keras default epsilon 1e-3) -> LeakyReLU(0.1); stride 2 = ZeroPadding2D(((1,0),(1,0))) + VALID;
+# shortcut = Add; route = concat; upsample = nearest x2; heads = linear Conv2D with bias).
+def _leaky(x):
+    return np.where(x >= 0, x, x * np.asarray(0.1, x.dtype))
+
+
+def yolov3_spec(num_classes=1):
+    spec, ci = [], [0]
+
+    def conv(cin, cout, k, bn=True):
+        i = ci[0]
+        ci[0] += 1
+        s = [('conv_%d/kernel' % i, (k, k, cin, cout))]
+        if bn:
+            s += [('bn_%d/%s' % (i, n), (cout,)) for n in ('gamma', 'beta', 'moving_mean', 'moving_variance')]
+        else:
+            s += [('conv_%d/bias' % i, (cout,))]
+        spec.extend(s)
+        return cout
+
+    c = conv(3, 32, 3)
+    for cout, blocks in ((64, 1), (128, 2), (256, 8), (512, 8), (1024, 4)):
+        c = conv(c, cout, 3)
+        for _ in range(blocks):
+            conv(cout, cout // 2, 1)
+            conv(cout // 2, cout, 3)
+    n_out = 3 * (5 + num_classes)
+
+    def head(cin, w):
+        conv(cin, w, 1), conv(w, 2 * w, 3), conv(2 * w, w, 1), conv(w, 2 * w, 3), conv(2 * w, w, 1)
+        conv(w, 2 * w, 3), conv(2 * w, n_out, 1, bn=False)
+
+    head(1024, 512)
+    conv(512, 256, 1)
+    head(256 + 512, 256)
+    conv(256, 128, 1)
+    head(128 + 256, 128)
+    return spec
+
+
+def yolov3_forward(x, p, num_classes=1):
+    """x [N,H,W,3] (letterboxed, /255) -> [y13, y26, y52] maps of 3*(5+classes) channels."""
+    from .nets import batchnorm, conv2d
+    ci = [0]
+
+    def cbl(x, k, stride):
+        i = ci[0]
+        ci[0] += 1
+        if stride == 2:
+            y = conv2d(x, p['conv_%d/kernel' % i], stride=2, pad=(1, 0, 1, 0))
+        else:
+            pd = 1 if k == 3 else 0
+            y = conv2d(x, p['conv_%d/kernel' % i], pad=(pd, pd, pd, pd))
+        return _leaky(batchnorm(y, p, 'bn_%d' % i, 1e-3))
+
+    def linear(x):
+        i = ci[0]
+        ci[0] += 1
+        return conv2d(x, p['conv_%d/kernel' % i], p['conv_%d/bias' % i])
+
+    y = cbl(x, 3, 1)
+    routes = {}
+    for cout, blocks in ((64, 1), (128, 2), (256, 8), (512, 8), (1024, 4)):
+        y = cbl(y, 3, 2)
+        for _ in range(blocks):
+            y = y + cbl(cbl(y, 1, 1), 3, 1)
+        routes[cout] = y
+
+    def head(y):
+        for k in (1, 3, 1, 3, 1):
+            y = cbl(y, k, 1)
+        return y, linear(cbl(y, 3, 1))
+
+    def up(y):
+        return np.repeat(np.repeat(y, 2, axis=1), 2, axis=2)
+
+    b, y13 = head(y)
+    b, y26 = head(np.concatenate([up(cbl(b, 1, 1)), routes[512]], axis=3))
+    b, y52 = head(np.concatenate([up(cbl(b, 1, 1)), routes[256]], axis=3))
+    return [y13, y26, y52]

@@ -77,3 +77,93 @@ def test_batched_detection_and_plain_nms(cuda):
     s = rng.uniform(0, 1, 300).astype(np.float32)
     s[10] = s[200]                                              # an exact tie
     assert list(yolov3.non_max_suppression(b, s, 50, 0.3)) == list(odet.non_max_suppression(b, s, 50, 0.3))
+
+
+# ------------------------------------------------------------------------------ the detector network
+def _yolo_params(num_classes=1):
+    from deep_insight_face.networks.weights import synth_params
+    return synth_params(odet.yolov3_spec(num_classes))
+
+
+def _frames(n, hw, seed=0):
+    return np.random.default_rng(seed).integers(0, 256, (n, hw, hw, 3), dtype=np.uint8).astype(np.float32) / np.float32(255)
+
+
+def test_yolov3_structure_matches_the_cfg():
+    """75 convolutions (72 with BN + leaky, 3 linear heads with bias), as the reference's cfg has;
+    when the reference tree is present, count its cfg sections too."""
+    import os
+    spec = odet.yolov3_spec(1)
+    kernels = [s for n, s in spec if n.endswith('/kernel')]
+    assert len(kernels) == 75 and len([n for n, _ in spec if n.endswith('/bias')]) == 3
+    assert kernels[-1][-1] == 18 and kernels[0] == (3, 3, 3, 32)
+    cfg = '/root/reference/deep_insight_face/detector/yolo_cfg/yolov3-face.cfg'
+    if os.path.exists(cfg):
+        txt = open(cfg).read()
+        assert txt.count('[convolutional]') == 75 and txt.count('[shortcut]') == 23
+        assert txt.count('[route]') == 4 and txt.count('[upsample]') == 2 and txt.count('[yolo]') == 3
+    from deep_insight_face.detector.run import yolo_v3_face
+    net = yolo_v3_face(1, 416)
+    assert dict(net.param_spec()) == dict(spec)
+    assert net.output_shapes == [(13, 13, 18), (26, 26, 18), (52, 52, 18)]
+    assert abs(net.flops_per_image / 1e9 - 65.3) < 0.2
+
+
+def test_yolov3_oracle_vs_torch():
+    import torch_ref
+    p = _yolo_params()
+    x = _frames(1, 96)
+    a = odet.yolov3_forward(x, p)
+    b = torch_ref.yolov3(x, p)
+    assert [t.shape for t in a] == [(1, 3, 3, 18), (1, 6, 6, 18), (1, 12, 12, 18)]
+    for u, v in zip(a, b):
+        np.testing.assert_allclose(u, v, rtol=2e-3, atol=2e-4 * np.abs(v).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,hw', [(2, 160), (1, 416)])
+def test_yolov3_gpu_vs_oracle(cuda, n, hw):
+    from deep_insight_face.detector.run import yolo_v3_face
+    net = yolo_v3_face(1, hw, max_batch=2)
+    net.init_synthetic(2024)
+    p = net.get_weights()
+    x = _frames(n, hw, seed=3)
+    got = net.predict_on_batch(x)
+    want = odet.yolov3_forward(x, p)
+    assert len(got) == 3
+    for g, w in zip(got, want):
+        assert g.shape == w.shape
+        np.testing.assert_allclose(g, w, rtol=2e-3, atol=2e-4 * np.abs(w).max())
+
+
+@pytest.mark.gpu
+def test_detection_pipeline_end_to_end(cuda):
+    """letterbox -> network -> decode -> NMS through the reference-named entry points, compared with
+    the oracle fed with the same (GPU-produced) maps, and with the oracle's own network forward."""
+    from PIL import Image
+    from deep_insight_face.detector import run, yolov3
+    net = run.yolo_v3_face(1, 416, max_batch=1)
+    p = _yolo_params()
+    for head in (58, 66, 74):                            # tame the random heads: exp(t_w) must stay finite
+        p['conv_%d/kernel' % head] = p['conv_%d/kernel' % head] * np.float32(1e-5)
+    p['conv_58/bias'] = p['conv_58/bias'].copy()      # make the coarse head fire: objectness bias up
+    p['conv_58/bias'][4::6] += 2.0
+    p['conv_58/bias'][5::6] += 2.0
+    for head in (66, 74):
+        p['conv_%d/bias' % head] = p['conv_%d/bias' % head].copy()
+        p['conv_%d/bias' % head][4::6] -= 6.0
+    net.set_weights(p)
+    img = Image.fromarray(np.random.default_rng(5).integers(0, 256, (300, 500, 3), dtype=np.uint8))
+    boxes, boxed = run.get_bounding_box(net, img, run.ANCHORS, 1, (416, 416), score_threshold=0.3)
+    assert boxed.size == (416, 416)
+    x = np.expand_dims(np.array(boxed, dtype='float32') / 255., 0)
+    maps = net.predict(x)
+    ob, os_, oc = odet.get_yolo_output(maps, odet.ANCHORS, 1, (300, 500), 20, 0.3, 0.5)
+    assert len(boxes) == len(ob) > 0
+    for (left, top, right, bottom), o in zip(boxes, ob):
+        np.testing.assert_allclose([top, left, bottom, right], o, rtol=2e-5, atol=2e-3)
+    det = run.YoloDetection(model=net, score=0.3)
+    crops, bbs = det(np.array(img))
+    assert len(crops) == len(boxes) and all(c.ndim == 3 for c in crops)
+    with pytest.raises(AssertionError, match='Invalid image format'):
+        det('nope')

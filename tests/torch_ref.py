@@ -152,3 +152,44 @@ def embed_nn4(x_nhwc, p):
     x = torch.from_numpy(x_nhwc).permute(0, 3, 1, 2).contiguous()
     with torch.no_grad():
         return nn4(x, p).numpy()
+
+
+# ---------------------------------------------------------------------------- YOLOv3-face
+def yolov3(x_nhwc, p):
+    import numpy as np
+    x = torch.from_numpy(x_nhwc).permute(0, 3, 1, 2).contiguous()
+    ci = [0]
+
+    def cbl(t, k, stride):
+        i = ci[0]
+        ci[0] += 1
+        w = _t(p, 'conv_%d/kernel' % i).permute(3, 2, 0, 1).contiguous()
+        if stride == 2:
+            t = F.conv2d(F.pad(t, (1, 0, 1, 0)), w, None, stride=2)
+        else:
+            t = F.conv2d(t, w, None, padding=1 if k == 3 else 0)
+        return F.leaky_relu(_bn(t, p, 'bn_%d' % i, 1e-3), 0.1)
+
+    def linear(t):
+        i = ci[0]
+        ci[0] += 1
+        return F.conv2d(t, _t(p, 'conv_%d/kernel' % i).permute(3, 2, 0, 1).contiguous(), _t(p, 'conv_%d/bias' % i))
+
+    with torch.no_grad():
+        y = cbl(x, 3, 1)
+        routes = {}
+        for cout, blocks in ((64, 1), (128, 2), (256, 8), (512, 8), (1024, 4)):
+            y = cbl(y, 3, 2)
+            for _ in range(blocks):
+                y = y + cbl(cbl(y, 1, 1), 3, 1)
+            routes[cout] = y
+
+        def head(t):
+            for k in (1, 3, 1, 3, 1):
+                t = cbl(t, k, 1)
+            return t, linear(cbl(t, 3, 1))
+
+        b, y13 = head(y)
+        b, y26 = head(torch.cat([F.interpolate(cbl(b, 1, 1), scale_factor=2, mode='nearest'), routes[512]], 1))
+        b, y52 = head(torch.cat([F.interpolate(cbl(b, 1, 1), scale_factor=2, mode='nearest'), routes[256]], 1))
+    return [np.ascontiguousarray(t.permute(0, 2, 3, 1).numpy()) for t in (y13, y26, y52)]
