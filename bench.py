@@ -43,6 +43,9 @@ WORKLOADS = {
                  'configs[2]: IResNet-100 512-d embed + ArcMargin logits (85742 classes), batch=512/GPU'),
     'r100_1m': ('iresnet100', 'v2', 512, 1_000_000,
                 'configs[3]: IResNet-100 embed, batch=512/GPU (4096 on 8 GPUs), 1M gallery row-sharded'),
+    'frames': ('resnet', 'v2', 256, 100_000,
+               'configs[4]: 256 raw 640x480 frames/GPU -> letterbox -> YOLOv3-face -> best box -> crop 112 -> '
+               'ResNet-50V2 embed -> 100k gallery match (the reference ships YOLOv3-face, not MTCNN)'),
 }
 ARC_CLASSES = 85_742     # MS1MV2 identities
 
@@ -51,6 +54,22 @@ def synthetic_gallery(rows, d, seed, device):
     g = torch.Generator(device='cpu').manual_seed(seed)
     x = torch.randn((rows, d), generator=g, dtype=torch.float32)
     return torch.nn.functional.normalize(x, dim=1).to(device)
+
+
+def synth_yolo_params(det):
+    """He-normal detector weights with the three linear heads tamed (kernels * 1e-5, objectness and
+    class logits biased to +2) so that exp() in the box decode stays finite and every frame yields
+    a detection -- the arithmetic per frame does not depend on the values."""
+    from deep_insight_face.networks.weights import synth_params
+    p = synth_params(det.param_spec(), seed=2025)
+    heads = [n[:-len('/bias')] for n in p if n.endswith('/bias')]
+    for h in heads:
+        p[h + '/kernel'] = p[h + '/kernel'] * np.float32(1e-5)
+        b = np.zeros_like(p[h + '/bias'])
+        b[4::6] = 2.0
+        b[5::6] = 2.0
+        p[h + '/bias'] = b
+    return p
 
 
 def measured_traffic(workload, batch):
@@ -170,8 +189,37 @@ def main():
     crops = torch.randint(0, 256, (batch, 112, 112, 3), generator=g, dtype=torch.uint8).to(dev)
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    pipe = None
+    if args.workload == 'frames':
+        from deep_insight_face.detector import run as drun
+        det = drun.yolo_v3_face(1, 416, max_batch=64)
+        dp = synth_yolo_params(det)
+        det.set_weights(dp)
+        det.set_input_transform(scale=1 / 255.)               # run.py:98 `/ 255.`, fused
+        pipe = drun.FramePipeline(det, model, None, margin=8, score=0.4)
+        frames = torch.randint(0, 256, (batch, 480, 640, 3), generator=g, dtype=torch.uint8).to(dev)
+        det_ms = []
+
+    def step_frames(i=None):
+        if i is not None:
+            ev[i][0].record()
+        boxes, _ = pipe.detect(frames)
+        faces = drun.crop_faces(frames, boxes, 8, 112)
+        if i is not None:
+            e_det = torch.cuda.Event(enable_timing=True)
+            e_det.record()
+            det_ms.append(e_det)
+        emb = model.embed(faces)
+        if i is not None:
+            ev[i][1].record()
+        idx, d = shard.match(emb, 1)
+        if i is not None:
+            ev[i][2].record()
+        return idx, d
 
     def step(i=None):
+        if pipe is not None:
+            return step_frames(i)
         if i is not None:
             ev[i][0].record()
         emb = model.embed(crops)
@@ -208,14 +256,17 @@ def main():
 
     if rank == 0:
         flops_embed = model.flops_per_image * batch            # algorithmic: 2 * MACs of every conv/dense
+        if pipe is not None:
+            flops_embed += det.flops_per_image * batch
         achieved = flops_embed / (embed_ms * 1e-3) / 1e12
         prof = model.profile(crops)
         conv_ms = sum(ms for _, k, _, ms in prof if k.startswith('conv_igemm'))
         conv_flops = sum(2 * macs * batch for _, k, macs, _ in prof if k.startswith('conv_igemm'))
         out = {
-            'metric': 'faces/sec embedding+match (112x112, 512-d)',
+            'metric': 'faces/sec embedding+match (112x112, 512-d)' if pipe is None else
+                      'frames/sec detect+crop+embed+match (640x480 frames, one face per frame)',
             'value': world * batch * args.steps / elapsed,
-            'unit': 'faces/s',
+            'unit': 'faces/s' if pipe is None else 'frames/s',
             'n_gpus': world,
             'steps': args.steps,
             'warmup': args.warmup,
@@ -229,7 +280,9 @@ def main():
                        'global_batch': world * batch, 'gallery_rows': gallery_rows,
                        'gallery_rows_per_gpu': hi - lo, 'emd': 512, 'metric': 'cosine',
                        'parallelism': 'dp%d + gallery row-shard' % world, 'backend': args.backend if world > 1 else None},
-            'phases_ms': {'embed': embed_ms, 'match': match_ms},
+            'phases_ms': ({'embed': embed_ms, 'match': match_ms} if pipe is None else
+                          {'detect+crop': float(np.mean([ev[i][0].elapsed_time(det_ms[i]) for i in range(args.steps)])),
+                           'detect+crop+embed': embed_ms, 'match': match_ms}),
             'roofline': {
                 'bound': 'mfma', 'kernel': 'conv_igemm_kernel (f32 MFMA implicit-GEMM conv; one launch group = the '
                                            '%d conv launches of one %s forward at batch %d)'
@@ -244,7 +297,7 @@ def main():
                           'tflops': 2.0 * world * batch * (hi - lo) * 512 / (match_ms * 1e-3) / 1e12},
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and pipe is None:
             out['cpu_baseline'] = cpu_baseline(arch, head, gallery_rows)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -99,3 +99,17 @@ def letterbox_image(image: Image.Image, size: typing.Tuple[int, int]) -> Image.I
     canvas = Image.new('RGB', size, (128, 128, 128))
     canvas.paste(image.resize((nw, nh), Image.BICUBIC), ((w - nw) // 2, (h - nh) // 2))
     return canvas
+
+
+def letterbox_batch(frames, size: int = 416) -> torch.Tensor:
+    """``letterbox_image`` for a whole batch on the device: uint8 [N,H,W,3] (ndarray or tensor)
+    -> uint8 CUDA tensor [N,size,size,3] (dif_letterbox; PIL BICUBIC semantics, rounding may
+    differ from PIL's fixed-point passes by one grey level)."""
+    dev = N.require_device()
+    t = torch.from_numpy(np.ascontiguousarray(frames)) if not torch.is_tensor(frames) else frames
+    if t.dim() != 4 or t.shape[3] != 3 or t.dtype != torch.uint8:
+        raise ValueError('expected uint8 frames [N,H,W,3], got %s %s' % (t.dtype, tuple(t.shape)))
+    t = t.to(dev).contiguous()
+    out = torch.empty((t.shape[0], size, size, 3), dtype=torch.uint8, device=dev)
+    N.check(N.lib.dif_letterbox(N.ptr(t), t.shape[0], t.shape[1], t.shape[2], N.ptr(out), size, N.stream_ptr()))
+    return out

@@ -83,6 +83,16 @@ int dif_nms(const float* boxes_dev, const float* scores_dev, int n_images, int n
             float score_threshold, float iou_threshold, uint8_t* alive_ws_dev, int32_t* keep_idx_dev,
             int32_t* keep_count_dev, void* stream);
 
+/* Image resampling around the detector, uint8 NHWC in and out.
+ * dif_letterbox: aspect-preserving BICUBIC resize (PIL semantics incl. antialiasing) onto a
+ *   size x size canvas of (128,128,128)                       detector/yolov3.py:108-119
+ * dif_crop_resize: per frame, box (left, top, right, bottom) + margin/2 per side, clamped
+ *   (detector/run.py:63-87), resampled to size x size by area coverage (cv2 INTER_AREA, which is what
+ *   predictions.py:93,154 selects); an empty / NaN box gives a black crop. */
+int dif_letterbox(const uint8_t* frames_dev, int n, int h, int w, uint8_t* out_dev, int size, void* stream);
+int dif_crop_resize(const uint8_t* frames_dev, int n, int h, int w, const float* boxes_ltrb_dev, float margin,
+                    uint8_t* out_dev, int size, void* stream);
+
 /* ------------------------------------------------------------------ gallery + 1:N match
  * The reference has no 1:N entry point; the semantics are utility.distance broadcast
  * over gallery rows + np.argmin (first minimum).  Housed Python-side under
