@@ -166,7 +166,7 @@ class DifEmbedder:
             raise ValueError('profile one batch of at most max_batch images')
         layout = N.LAYOUT_NHWC if tuple(t.shape[1:]) == self.input_shape else N.LAYOUT_NCHW
         dtype = N.DTYPE_U8 if t.dtype == torch.uint8 else N.DTYPE_F32
-        out = torch.empty((n,) + self.output_shape, dtype=torch.float32, device=dev)
+        out = torch.empty((n * sum(int(np.prod(s)) for s in self.output_shapes),), dtype=torch.float32, device=dev)
         k = N.lib.dif_net_launch_count(self._h)
         ms = (ctypes.c_float * k)()
         N.check(N.lib.dif_net_embed_profile(self._h, N.ptr(t), n, layout, dtype, N.ptr(out), N.stream_ptr(), ms))
