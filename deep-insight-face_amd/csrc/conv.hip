@@ -433,6 +433,11 @@ __global__ __launch_bounds__(T::NT, 2) void conv_igemm_kernel(const ConvArgs a) 
   const int I = tiles_m * tiles_n * KS;                       // < 2^31 (checked by conv_run)
   const int beg = (int)((int64_t)I * p / P), end = (int)((int64_t)I * (p + 1) / P);
 
+  if (a.trace && tid == 0) {
+    a.trace[blockIdx.x * 4] = __builtin_amdgcn_s_memrealtime();
+    a.trace[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 4 /* HW_ID, 32 bits */) |
+                                  ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20 /* XCC_ID */) << 32);
+  }
   int it = beg;
   while (it < end) {
     int tile, kb, mt, nt;
@@ -458,6 +463,7 @@ __global__ __launch_bounds__(T::NT, 2) void conv_igemm_kernel(const ConvArgs a) 
         gemm_mainloop<T>(al, bl, k0, k1, smem, acc);
     };
     run(kb, ke);
+    if (a.trace && tid == 0 && it == beg) a.trace[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
 
     if (kb != 0) {
       // not the owner of this tile: publish the partial accumulators (fragment order, 16 B per lane)
@@ -529,6 +535,7 @@ __global__ __launch_bounds__(T::NT, 2) void conv_igemm_kernel(const ConvArgs a) 
     }
     it += ke - kb;
   }
+  if (a.trace && tid == 0) a.trace[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
 }
 
 static int g_num_cus = 0;

@@ -15,8 +15,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void input_convert_kernel(const InputArgs a) {
   const int64_t npix = (int64_t)a.N * a.H * a.W;
   const int64_t HW = (int64_t)a.H * a.W;
-  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256) {
+  const bool bgr = a.bgr & DIF_INPUT_BGR, hflip = a.bgr & DIF_INPUT_HFLIP;
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < npix; q += (int64_t)gridDim.x * 256) {
     float v[3];
+    int64_t p = q;                                   // source pixel
+    if (hflip) {
+      const int w = (int)(q % a.W);
+      p = q - w + (a.W - 1 - w);
+    }
     if (a.layout == DIF_LAYOUT_NHWC) {
       if (a.dtype == DIF_DTYPE_U8) {
         const uint8_t* s = static_cast<const uint8_t*>(a.x) + p * 3;
@@ -36,11 +42,11 @@ __global__ __launch_bounds__(256) void input_convert_kernel(const InputArgs a) {
       }
     }
     f32x4 o;
-    o[0] = (a.bgr ? v[2] : v[0]) * a.scale + a.bias[0];
+    o[0] = (bgr ? v[2] : v[0]) * a.scale + a.bias[0];
     o[1] = v[1] * a.scale + a.bias[1];
-    o[2] = (a.bgr ? v[0] : v[2]) * a.scale + a.bias[2];
+    o[2] = (bgr ? v[0] : v[2]) * a.scale + a.bias[2];
     o[3] = 0.f;
-    *reinterpret_cast<f32x4*>(a.y + p * 4) = o;
+    *reinterpret_cast<f32x4*>(a.y + q * 4) = o;
   }
 }
 

@@ -76,6 +76,9 @@ struct ConvArgs {
   unsigned sk_epoch;
   int sk_max_blocks;
   int sk_spin_limit;    // polls before the owner computes a missing K range itself; < 0: always (test hook)
+  // development aid (tools/ubench/conv_trace.hip), null in the library: 4 x u64 per hardware block =
+  // s_memrealtime (100 MHz) at entry / after the first mainloop / at exit, and the HW_ID register
+  unsigned long long* trace;
   // launch-invariant divisors (filled by conv_run)
   FastDiv fd_howo, fd_wo, fd_cin, fd_kw, fd_ks, fd_tiles_n, fd_taps;
 };
@@ -115,7 +118,7 @@ struct InputArgs {
   int layout, dtype; // DIF_LAYOUT_*, DIF_DTYPE_*
   float scale;
   float bias[3];
-  int bgr;
+  int bgr;           // DIF_INPUT_* flags
 };
 int input_convert_run(const InputArgs& a, hipStream_t st);
 

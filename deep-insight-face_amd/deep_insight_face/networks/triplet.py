@@ -89,10 +89,26 @@ class DifEmbedder:
     def save_weights(self, path):
         W.save_npz(path, self.get_weights())
 
-    def set_input_transform(self, scale=1.0, bias=(0.0, 0.0, 0.0), bgr=False):
-        """y[c] = x[2-c if bgr else c] * scale + bias[c], fused into the first kernel."""
+    def set_input_transform(self, scale=1.0, bias=(0.0, 0.0, 0.0), bgr=False, hflip=False):
+        """y[c] = x[2-c if bgr else c] * scale + bias[c] (and a left-right mirror with ``hflip``),
+        fused into the first kernel."""
         b = (ctypes.c_float * 3)(*[float(v) for v in bias])
-        N.check(N.lib.dif_net_set_input_transform(self._h, float(scale), b, int(bool(bgr))))
+        self._transform = (float(scale), tuple(float(v) for v in bias), bool(bgr), bool(hflip))
+        N.check(N.lib.dif_net_set_input_transform(self._h, float(scale), b, int(bool(bgr)) | (2 if hflip else 0)))
+
+    def embed_flipped_concat(self, x, layout=None):
+        """[embed(x), embed(mirror(x))] concatenated along the feature axis -> [N, 2*emd]: the
+        ``use_flipped_images`` option of the evaluation entry point (scripts/insight_face.py:117-118,
+        'Concatenates embeddings for the image and its horizontally flipped counterpart').  The
+        mirror happens while the first kernel reads the input; the images are not copied."""
+        scale, bias, bgr, hflip = getattr(self, '_transform', (1.0, (0.0, 0.0, 0.0), False, False))
+        a = self.embed(x, layout)
+        self.set_input_transform(scale, bias, bgr, not hflip)
+        try:
+            b = self.embed(x, layout)
+        finally:
+            self.set_input_transform(scale, bias, bgr, hflip)
+        return torch.cat([a, b], dim=1)
 
     def _finalize(self):
         if not self._ready:

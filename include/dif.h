@@ -36,6 +36,9 @@ extern "C" {
 #define DIF_LAYOUT_NCHW 1 /* north_star's torch-side layout */
 #define DIF_DTYPE_F32 0
 #define DIF_DTYPE_U8 1
+/* flags of dif_net_set_input_transform */
+#define DIF_INPUT_BGR 1   /* swap R and B (keras vgg16 preprocess_input, predictions.py:95) */
+#define DIF_INPUT_HFLIP 2 /* mirror every image left-right (scripts/insight_face.py:117-118 use_flipped_images) */
 
 typedef struct dif_gallery dif_gallery;
 typedef struct dif_net dif_net;
@@ -132,8 +135,9 @@ int dif_net_set_param(dif_net* net, const char* name, const float* data_host, in
 int dif_net_get_param(const dif_net* net, const char* name, float* data_host, int64_t count);
 /* input transform applied while converting to the internal NHWC4 f32 layout:
  * y[c] = x[bgr ? 2-c : c] * scale + bias[c]   (predictions.py:94,154 `* rescale`;
- * predictions.py:95 keras vgg16 preprocess_input = BGR swap + mean subtraction) */
-int dif_net_set_input_transform(dif_net* net, float scale, const float bias[3], int bgr);
+ * predictions.py:95 keras vgg16 preprocess_input = BGR swap + mean subtraction);
+ * flags = DIF_INPUT_BGR | DIF_INPUT_HFLIP (1 keeps meaning "bgr") */
+int dif_net_set_input_transform(dif_net* net, float scale, const float bias[3], int flags);
 /* pack weights for the kernels, upload, and size the activation workspace */
 int dif_net_finalize(dif_net* net, int max_batch);
 int dif_net_output_dim(const dif_net* net, int64_t shape[3]); /* {emd,1,1} or {C,H,W} for v3 */

@@ -130,6 +130,29 @@ def test_bgr_mean_transform(cuda):
     model.close()
 
 
+def test_flipped_concat(cuda):
+    """use_flipped_images (scripts/insight_face.py:117-118): embeddings of the image and of its
+    mirror, concatenated; the mirror is fused into the input kernel for every input form."""
+    import torch
+    model, p = build('resnet', 'v2', 512, max_batch=4)
+    u8 = crops_u8(3, seed=8)
+    x = scaled(u8)
+    want = np.concatenate([nets.embed(x, p, 'resnet', 512, 'v2'),
+                           nets.embed(x[:, :, ::-1, :].copy(), p, 'resnet', 512, 'v2')], axis=1)
+    got = model.embed_flipped_concat(x).cpu().numpy()
+    assert got.shape == (3, 1024)
+    assert cosine_gap(got[:, :512], want[:, :512]).max() < TOL
+    assert cosine_gap(got[:, 512:], want[:, 512:]).max() < TOL
+    # bitwise: fused mirror == mirroring the array first; NCHW uint8 input too; transform restored
+    assert np.array_equal(got[:, 512:], model.predict_on_batch(x[:, :, ::-1, :].copy()))
+    model.set_input_transform(scale=1 / 255.)
+    nchw = torch.from_numpy(u8).permute(0, 3, 1, 2).contiguous()
+    got2 = model.embed_flipped_concat(nchw).cpu().numpy()
+    assert np.array_equal(got2[:, 512:], model.predict_on_batch(u8[:, :, ::-1, :].copy()))
+    assert np.array_equal(got2[:, :512], model.predict_on_batch(u8))
+    model.close()
+
+
 def test_weights_roundtrip(cuda, tmp_path):
     model, p = build('resnet', 'v1', 128, max_batch=2)
     x = scaled(crops_u8(2))

@@ -1,0 +1,115 @@
+// Development aid: runs ONE convolution layer through the library's own dif::conv_run with the
+// in-kernel trace enabled and prints where the blocks spend their time.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I deep-insight-face_amd/csrc tools/ubench/conv_trace.hip \
+//         -L deep-insight-face_amd/lib -ldif -Wl,-rpath,$PWD/deep-insight-face_amd/lib -o /tmp/conv_trace
+//   conv_trace N H W Cin Cout K stride pad res pre korder
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <vector>
+#include "ops.hpp"
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+int main(int argc, char** argv) {
+  if (argc < 12) { printf("usage: N H W Cin Cout K stride pad res pre korder\n"); return 1; }
+  int N = atoi(argv[1]), H = atoi(argv[2]), W = atoi(argv[3]), Cin = atoi(argv[4]), Cout = atoi(argv[5]);
+  int K = atoi(argv[6]), stride = atoi(argv[7]), pad = atoi(argv[8]), res = atoi(argv[9]), pre = atoi(argv[10]);
+  int korder = atoi(argv[11]);
+  int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
+  int Kdim = K * K * Cin, Kpad = (Kdim + 31) / 32 * 32;
+  int64_t M = (int64_t)N * Ho * Wo;
+  size_t nx = (size_t)N * H * W * Cin, nw = (size_t)Cout * Kpad, ny = (size_t)M * Cout;
+  std::vector<float> hx(nx), hw(nw), hv(std::max(Cin, Cout), 1.0f);
+  for (auto& v : hx) v = (rand() % 2001 - 1000) * 1e-3f;
+  for (auto& v : hw) v = (rand() % 2001 - 1000) * 1e-4f;
+  float *x, *w, *y, *r, *sc, *sh, *slab;
+  unsigned* flag;
+  unsigned long long* trace;
+  const int maxb = dif::conv_max_blocks();
+  CK(hipMalloc(&x, nx * 4)); CK(hipMalloc(&w, nw * 4)); CK(hipMalloc(&y, ny * 4)); CK(hipMalloc(&r, ny * 4));
+  CK(hipMalloc(&sc, hv.size() * 4)); CK(hipMalloc(&sh, hv.size() * 4));
+  CK(hipMalloc(&slab, (size_t)maxb * dif::conv_slab_floats() * 4)); CK(hipMalloc(&flag, maxb * 4));
+  const int64_t max_tiles = std::max<int64_t>(((M + 63) / 64) * ((Cout + 63) / 64), maxb);
+  CK(hipMalloc(&trace, (size_t)max_tiles * 32));
+  CK(hipMemcpy(x, hx.data(), nx * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(w, hw.data(), nw * 4, hipMemcpyHostToDevice));
+  CK(hipMemset(r, 0, ny * 4)); CK(hipMemset(flag, 0, maxb * 4));
+  CK(hipMemcpy(sc, hv.data(), hv.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemset(sh, 0, hv.size() * 4));
+  dif::ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.w = w; a.y = y; a.scale = sc; a.shift = sh; a.res = res ? r : nullptr;
+  if (pre) { a.pre_scale = sc; a.pre_shift = sh; a.pre_act = dif::ACT_RELU; }
+  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.KH = a.KW = K; a.stride = stride;
+  a.pad_t = a.pad_l = pad; a.Kpad = Kpad; a.k_order = korder; a.M = (int)M; a.act = dif::ACT_RELU;
+  a.res_H = Ho; a.res_W = Wo; a.res_stride = 1;
+  a.y_ld = Cout; a.y_H = Ho; a.y_W = Wo;
+  a.sk_slab = slab; a.sk_flag = flag; a.sk_max_blocks = maxb; a.sk_spin_limit = 1 << 20;
+  unsigned epoch = 0;
+  hipStream_t st = nullptr;
+  for (int i = 0; i < 5; ++i) { a.sk_epoch = ++epoch; if (dif::conv_run(a, -1, st)) { printf("conv_run failed\n"); return 1; } }
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const int reps = 20;
+  CK(hipEventRecord(e0, st));
+  for (int i = 0; i < reps; ++i) { a.sk_epoch = ++epoch; dif::conv_run(a, -1, st); }
+  CK(hipEventRecord(e1, st));
+  CK(hipEventSynchronize(e1));
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= reps;
+  const double flops = 2.0 * M * Cout * Kdim;
+  printf("M=%lld N=%d K=%d (KS=%d)  %.4f ms  %.1f TFLOP/s  ideal@144TF %.1f us\n", (long long)M, Cout, Kdim, Kpad / 32,
+         ms, flops / ms / 1e9, flops / 144e12 * 1e6);
+  // traced run
+  CK(hipMemset(trace, 0, (size_t)max_tiles * 32));
+  a.trace = trace; a.sk_epoch = ++epoch;
+  dif::conv_run(a, -1, st);
+  CK(hipDeviceSynchronize());
+  std::vector<unsigned long long> t((size_t)max_tiles * 4);
+  CK(hipMemcpy(t.data(), trace, t.size() * 8, hipMemcpyDeviceToHost));
+  int64_t nb = 0;
+  unsigned long long tmin = ~0ull, tmax = 0;
+  for (int64_t b = 0; b < max_tiles; ++b) if (t[b * 4]) { ++nb; tmin = std::min(tmin, t[b * 4]); tmax = std::max(tmax, t[b * 4 + 2]); }
+  double ml = 0, ep = 0;
+  std::vector<double> mls, eps, starts;
+  std::map<unsigned long long, int> per_cu;
+  for (int64_t b = 0; b < max_tiles; ++b) if (t[b * 4]) {
+    mls.push_back((t[b * 4 + 1] - t[b * 4]) * 0.01); eps.push_back((t[b * 4 + 2] - t[b * 4 + 1]) * 0.01);
+    starts.push_back((t[b * 4] - tmin) * 0.01);
+    ml += mls.back(); ep += eps.back();
+    const unsigned hw = (unsigned)t[b * 4 + 3];
+    const unsigned long long key = ((t[b * 4 + 3] >> 32) << 16) | (((hw >> 13) & 7) << 8) | ((hw >> 8) & 15);   // xcc, se, cu
+    per_cu[key]++;
+  }
+  if (getenv("SHOW_MAP")) {
+    for (int64_t b = 0; b < std::min<int64_t>(max_tiles, 160); ++b) if (t[b * 4]) {
+      const unsigned hw = (unsigned)t[b * 4 + 3];
+      printf("  block %4lld: xcc %llu se %u sh %u cu %2u simd %u wave %u  start %.2f us\n", (long long)b, t[b * 4 + 3] >> 32,
+             (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 15, (hw >> 4) & 3, hw & 15, (t[b * 4] - tmin) * 0.01);
+    }
+  }
+  std::sort(mls.begin(), mls.end()); std::sort(eps.begin(), eps.end());
+  printf("blocks %lld on %zu CUs; span %.1f us; first-mainloop mean %.2f us (p10 %.2f p50 %.2f p90 %.2f); rest-of-block mean %.2f us (p10 %.2f p50 %.2f p90 %.2f)\n",
+         (long long)nb, per_cu.size(), (tmax - tmin) * 0.01, ml / nb, mls[nb / 10], mls[nb / 2], mls[nb * 9 / 10], ep / nb,
+         eps[nb / 10], eps[nb / 2], eps[nb * 9 / 10]);
+  // concurrency over time: blocks alive in 2 us buckets, and how many are in their mainloop
+  const double span = (tmax - tmin) * 0.01;
+  const int nbk = (int)(span / 2.0) + 1;
+  std::vector<double> alive(nbk, 0), inml(nbk, 0);
+  for (int64_t b = 0; b < max_tiles; ++b) if (t[b * 4]) {
+    const double s = (t[b * 4] - tmin) * 0.01, m = (t[b * 4 + 1] - tmin) * 0.01, e = (t[b * 4 + 2] - tmin) * 0.01;
+    for (int k = 0; k < nbk; ++k) {
+      const double lo = k * 2.0, hi = lo + 2.0;
+      alive[k] += std::max(0.0, std::min(hi, e) - std::max(lo, s)) / 2.0;
+      inml[k] += std::max(0.0, std::min(hi, m) - std::max(lo, s)) / 2.0;
+    }
+  }
+  printf("t(us): alive / in-first-mainloop (avg blocks)\n");
+  for (int k = 0; k < nbk; ++k) printf("  %5.0f: %7.1f %7.1f\n", k * 2.0, alive[k], inml[k]);
+  return 0;
+}
