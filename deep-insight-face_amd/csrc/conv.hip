@@ -314,11 +314,46 @@ __device__ __forceinline__ f32x4 load4_or(const float* p, int c, float dflt) {
   return f32x4{dflt, dflt, dflt, dflt};
 }
 
+// The shortcut tile of one output tile, in the epilogue's thread mapping (16 bytes per lane along
+// the channel axis).  Loaded either from the mainloop's tail hook (latency hidden behind the last
+// K-step) or at the start of the epilogue.
+template <class T>
+struct EpiRes {
+  static constexpr int CPR = T::BN / 4;          // float4 chunks per tile row
+  static constexpr int RPP = T::NT / CPR;        // rows per pass
+  static constexpr int ITER = T::BM / RPP;
+  f32x4 rv[ITER];
+  __device__ __forceinline__ void load(const ConvArgs& a, int m0, int n0) {
+    const int tid = threadIdx.x;
+    const int c = n0 + (tid % CPR) * 4;
+    const int r0 = tid / CPR;
+    const bool strided_res = (a.res_stride != 1 || a.res_H != a.Ho || a.res_W != a.Wo);
+    const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+      const int row = m0 + r0 + i * RPP;
+      rv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (row < a.M && c < a.Cout) {
+        int64_t ri = row;
+        if (strided_res) {
+          const int img = row / HoWo;
+          const int rr = row - img * HoWo;
+          const int ho = rr / a.Wo;
+          const int wo = rr - ho * a.Wo;
+          ri = ((int64_t)img * a.res_H + (int64_t)ho * a.res_stride) * a.res_W + (int64_t)wo * a.res_stride;
+        }
+        rv[i] = *reinterpret_cast<const f32x4*>(a.res + ri * a.Cout + c);
+      }
+    }
+  }
+};
+
 // Stages the accumulator tile in LDS, then applies the epilogue with 16-byte accesses
-// along the channel axis.  Ends on a barrier (LDS is free afterwards).
+// along the channel axis.  Ends on a barrier (LDS is free afterwards).  `er` already holds the
+// shortcut tile when `res_loaded`.
 template <class T>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T::WM][T::WN], int m0, int n0,
-                                              float* smem) {
+                                              float* smem, EpiRes<T>& er, bool res_loaded) {
   constexpr int WM = T::WM, WN = T::WN;
   constexpr int CS = T::BN + 4;                 // LDS row pitch in floats (16-B aligned, rows shifted by 4 banks)
   constexpr int CPR = T::BN / 4;                // float4 chunks per tile row
@@ -344,27 +379,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
     const bool plain_out = (a.y_H == a.Ho && a.y_W == a.Wo && a.y_oy == 0 && a.y_ox == 0);
     const f32x4 sc = load4_or(a.scale, c, 1.f), sh = load4_or(a.shift, c, 0.f), al = load4_or(a.alpha, c, 0.f);
     const f32x4 sc2 = load4_or(a.scale2, c, 1.f), sh2 = load4_or(a.shift2, c, 0.f), al2 = load4_or(a.alpha2, c, 0.f);
-    const bool strided_res = a.res != nullptr && (a.res_stride != 1 || a.res_H != a.Ho || a.res_W != a.Wo);
-    const int HoWo = a.Ho * a.Wo;
-    f32x4 rv[ITER];
-    if (a.res) {
-#pragma unroll
-      for (int i = 0; i < ITER; ++i) {
-        const int row = m0 + r0 + i * RPP;
-        rv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (row < a.M) {
-          int64_t ri = row;
-          if (strided_res) {
-            const int img = row / HoWo;
-            const int rr = row - img * HoWo;
-            const int ho = rr / a.Wo;
-            const int wo = rr - ho * a.Wo;
-            ri = ((int64_t)img * a.res_H + (int64_t)ho * a.res_stride) * a.res_W + (int64_t)wo * a.res_stride;
-          }
-          rv[i] = *reinterpret_cast<const f32x4*>(a.res + ri * a.Cout + c);
-        }
-      }
-    }
+    if (a.res && !res_loaded) er.load(a, m0, n0);
 #pragma unroll
     for (int i = 0; i < ITER; ++i) {
       const int rl = r0 + i * RPP;
@@ -376,7 +391,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
         for (int j = 0; j < 4; ++j) {
           float t = fmaf(av[j], sc[j], sh[j]);
           t = apply_act(t, a.act, al[j]);
-          if (a.res) t += rv[i][j];
+          if (a.res) t += er.rv[i][j];
           v[j] = t;
           v2[j] = apply_act(fmaf(t, sc2[j], sh2[j]), a.act2, al2[j]);
         }
@@ -417,7 +432,7 @@ __device__ __forceinline__ int xcd_remap(int b, int P) {
 // AM (A-operand gather mode): 0 general, 1 pointwise (1x1, no padding, Cin % 32 == 0),
 // 2 multi-tap with Cin % 32 == 0 and channel-block-major K
 template <class T, bool PRE, bool DMA, int AM>
-__global__ __launch_bounds__(T::NT, 2) void conv_igemm_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const ConvArgs a) {
   static_assert(!(PRE && DMA), "pre-activation needs register staging");
   static_assert(!(AM != 0 && DMA), "the specialised loaders are register-staged");
   constexpr int WM = T::WM, WN = T::WN;
@@ -456,13 +471,18 @@ __global__ __launch_bounds__(T::NT, 2) void conv_igemm_kernel(const ConvArgs a) 
     using BLoad = typename std::conditional<DMA, DmaRowLoader<T::NB, T::RP>, RowLoader<T::NB, T::RP>>::type;
     ALoad al(a, m0);
     BLoad bl(a.w + (int64_t)n0 * a.Kpad, (int64_t)a.Cout - n0, a.Kpad);
-    auto run = [&](int k0, int k1) {
+    // this block computes the whole tile: fetch the shortcut tile behind the last K-step
+    const bool whole = !DMA && kb == 0 && ke == KS;
+    EpiRes<T> er;
+    auto run = [&](int k0, int k1, bool prefetch_res) {
       if constexpr (DMA)
         gemm_mainloop_dma<T>(al, bl, k0, k1, smem, acc);
       else
-        gemm_mainloop<T>(al, bl, k0, k1, smem, acc);
+        gemm_mainloop2<T>(al, bl, k0, k1, smem, acc, [&] {
+          if (prefetch_res && a.res) er.load(a, m0, n0);
+        });
     };
-    run(kb, ke);
+    run(kb, ke, whole);
     if (a.trace && tid == 0 && it == beg) a.trace[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
 
     if (kb != 0) {
@@ -527,11 +547,11 @@ __global__ __launch_bounds__(T::NT, 2) void conv_igemm_kernel(const ConvArgs a) 
         } else {
           // the partner never showed up (not co-resident): compute its K range here instead of
           // waiting for ever -- slower, still correct
-          run(q_kb, q_ke);
+          run(q_kb, q_ke, false);
         }
         kdone = q_ke;
       }
-      conv_epilogue<T>(a, acc, m0, n0, smem);
+      conv_epilogue<T>(a, acc, m0, n0, smem, er, whole);
     }
     it += ke - kb;
   }

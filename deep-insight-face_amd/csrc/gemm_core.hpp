@@ -47,6 +47,9 @@ struct Tile {
   static constexpr int NB = BN / RP;
   static constexpr int LDS_FLOATS = 2 * (BM + BN) * LDS_STRIDE;
   static constexpr int LDS_BYTES = LDS_FLOATS * 4;
+  // blocks per CU the kernels are built for: LDS-limited (160 KiB); 4 blocks of 4 waves = 4 waves per SIMD,
+  // i.e. at most 128 VGPRs -- handed to __launch_bounds__ so the compiler holds that line
+  static constexpr int MIN_BLOCKS = LDS_BYTES * 4 <= 160 * 1024 ? 4 : 2;
   static_assert(BM % RP == 0 && BN % RP == 0, "tile rows must be a multiple of the staging pass");
   __device__ static __forceinline__ int wave_row() { return (threadIdx.x >> 6) / WGN; }
   __device__ static __forceinline__ int wave_col() { return (threadIdx.x >> 6) % WGN; }
@@ -134,6 +137,78 @@ __device__ __forceinline__ void gemm_mainloop(ALoader& al, BLoader& bl, int kbeg
     }
     __syncthreads();
   }
+}
+
+// Variant used by the convolution kernel.  Same data movement, plus
+//  * the last K-step is peeled out of the loop and preceded by `tail()`: the caller issues the
+//    loads its epilogue will need (the shortcut tile) there, so their latency hides behind the
+//    last 16 MFMAs -- the operand staging registers are dead by then, so this costs no VGPRs;
+// (Fetching operands TWO K-steps ahead through a second set of staging registers was measured: at the
+// 128-VGPR budget of four waves per SIMD it spills, and loses 5-35 % on every layer class.)
+template <class T, class ALoader, class BLoader, class Tail>
+__device__ __forceinline__ void gemm_mainloop2(ALoader& al, BLoader& bl, int kbeg, int kend, float* lds,
+                                               f32x16 (&acc)[T::WM][T::WN], Tail&& tail) {
+  constexpr int WM = T::WM, WN = T::WN, BM = T::BM, BN = T::BN, NA = T::NA, NB = T::NB, RP = T::RP;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wr = T::wave_row(), wc = T::wave_col();
+  constexpr int BUF = (BM + BN) * LDS_STRIDE;
+  constexpr int OFFB = BM * LDS_STRIDE;
+  const int st_off = (tid >> 3) * LDS_STRIDE + (tid & 7) * 4;
+  const int fr_off = (lane & 31) * LDS_STRIDE + 8 * (lane >> 5);
+
+  auto mfma_step = [&](int cur) {
+    const float* pa = lds + cur * BUF + (wr * WM * 32) * LDS_STRIDE + fr_off;
+    const float* pb = lds + cur * BUF + OFFB + (wc * WN * 32) * LDS_STRIDE + fr_off;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      f32x4 fa[WM][2], fb[WN][2];
+#pragma unroll
+      for (int m = 0; m < WM; ++m) {
+        fa[m][0] = *reinterpret_cast<const f32x4*>(pa + m * 32 * LDS_STRIDE + 16 * s);
+        fa[m][1] = *reinterpret_cast<const f32x4*>(pa + m * 32 * LDS_STRIDE + 16 * s + 4);
+      }
+#pragma unroll
+      for (int n = 0; n < WN; ++n) {
+        fb[n][0] = *reinterpret_cast<const f32x4*>(pb + n * 32 * LDS_STRIDE + 16 * s);
+        fb[n][1] = *reinterpret_cast<const f32x4*>(pb + n * 32 * LDS_STRIDE + 16 * s + 4);
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+          for (int n = 0; n < WN; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[m][t >> 2][t & 3], fb[n][t >> 2][t & 3],
+                                                             acc[m][n], 0, 0, 0);
+    }
+  };
+  auto stage = [&](int buf, f32x4 (&ra)[NA], f32x4 (&rb)[NB]) {
+    float* wa = lds + buf * BUF + st_off;
+    al.finish(ra);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(wa + i * RP * LDS_STRIDE) = ra[i];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(wa + OFFB + i * RP * LDS_STRIDE) = rb[i];
+  };
+
+  f32x4 ra[NA], rb[NB];
+  al.load(kbeg, ra);
+  bl.load(kbeg, rb);
+  stage(0, ra, rb);
+  __syncthreads();
+  int ks = kbeg;
+  for (; ks + 1 < kend; ++ks) {
+    const int cur = (ks - kbeg) & 1;
+    al.load(ks + 1, ra);
+    bl.load(ks + 1, rb);
+    mfma_step(cur);
+    stage(cur ^ 1, ra, rb);
+    __syncthreads();
+  }
+  tail();
+  mfma_step((ks - kbeg) & 1);
+  __syncthreads();
 }
 
 template <class T>
