@@ -109,18 +109,21 @@ def test_batched_eval_loop(cuda, model):
 
 
 def test_two_lane_forward_matches_single_lane(cuda, monkeypatch):
-    """Batches >= 128 are split over two lanes (caller's stream + an internal HIP stream, separate
+    """With two lanes batches >= 64 are split over two lanes (caller's stream + an internal HIP stream, separate
     activation buffers): results must equal the single-lane forward up to float32 rounding, for
     ragged splits too, and a few rows are checked against the oracle."""
     from deep_insight_face.networks.triplet import DifEmbedder
     n = 131
     x = crops_u8(n, seed=11).astype(np.float32) / np.float32(255)
+    monkeypatch.setenv('DIF_STREAMS', '2')                         # (the default picks by work per launch)
     two = DifEmbedder('resnet', 'v2', 128, (112, 112, 3), max_batch=160).init_synthetic(7)
+    two._finalize()                                                # the lane count is fixed at finalize
     monkeypatch.setenv('DIF_STREAMS', '1')
     one = DifEmbedder('resnet', 'v2', 128, (112, 112, 3), max_batch=160).init_synthetic(7)
+    one._finalize()
+    monkeypatch.delenv('DIF_STREAMS')
     a = two.predict_on_batch(x)
     b = one.predict_on_batch(x)
-    monkeypatch.delenv('DIF_STREAMS')
     assert a.shape == (n, 128) and np.all(np.isfinite(a))
     assert cosine_gap(a, b).max() < 1e-6
     assert np.array_equal(two.predict_on_batch(x), a)             # deterministic
