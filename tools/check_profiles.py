@@ -33,6 +33,10 @@ def main():
         shutil.copy(ks, os.path.join(PROF, '%s_%s_b256_kernel_stats.csv' % (ROUND, w)))
         shutil.copy(os.path.join(OUT, 'layers_%s.txt' % w), os.path.join(PROF, '%s_%s_b256_layers.txt' % (ROUND, w)))
         shutil.copy(os.path.join(OUT, 'bench_%s.json' % w), os.path.join(PROF, '%s_%s_b256_bench.json' % (ROUND, w)))
+        pm = latest('pm_%s/*/*_counter_collection.csv' % w)
+        if pm:
+            with open(os.path.join(PROF, '%s_%s_b256_mfma_util.json' % (ROUND, w)), 'w') as fh:
+                subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', 'pmc_mfma.py'), pm], stdout=fh)
         with open(os.path.join(PROF, '%s_%s_b256_hbm_traffic.json' % (ROUND, w)), 'w') as fh:
             subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', 'pmc_traffic.py'), pf, pw, '5'], stdout=fh)
         conv_ns, conv_calls = 0.0, 0
@@ -44,7 +48,7 @@ def main():
         traffic = json.load(open(os.path.join(PROF, '%s_%s_b256_hbm_traffic.json' % (ROUND, w))))['total']
         lines.append('%-4s ONE lane (DIF_STREAMS=1): %d conv launches/forward, sum of conv kernel durations %.3f ms/forward '
                      '(rocprofv3 kernel-trace) vs HIP-event forward %.3f ms (%.1f TFLOP/s, frac %.3f)\n'
-                     '     TWO lanes (default): HIP-event forward %.3f ms, %.1f TFLOP/s, frac %.3f, %.0f faces/s incl. match | '
+                     '     default executor: HIP-event forward %.3f ms, %.1f TFLOP/s, frac %.3f, %.0f faces/s incl. match | '
                      'fabric traffic %.1f GB/forward'
                      % (w, conv_calls // forwards_ks, conv_ns / forwards_ks / 1e6,
                         bench1['roofline']['forward_ms_hip_events'], bench1['roofline']['achieved'], bench1['roofline']['frac'],

@@ -9,8 +9,11 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for w in r50 r100; do
   export DIF_STREAMS=1
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ks1_$w -- python3 bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/ks1_$w.log 2>&1
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pm_$w -- python3 bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/pm_$w.log 2>&1
   unset DIF_STREAMS
+  export DIF_STREAMS=2     # the "two lanes" files (IResNet-100's default; ResNet50V2 defaults to one lane)
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ks_$w -- python3 bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/ks_$w.log 2>&1
+  unset DIF_STREAMS
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pf_$w -- python3 bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/pf_$w.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pw_$w -- python3 bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/pw_$w.log 2>&1
 done
