@@ -645,9 +645,7 @@ static int launch_conv_pre(const ConvArgs& a, hipStream_t st) {
 int conv_tile_choice(int64_t M, int Cout, int Kpad) {
   // 0: 128x128, 1: 128x64, 2: 64x128, 3: 64x64
   static const int forced = getenv("DIF_CONV_TILE") ? atoi(getenv("DIF_CONV_TILE")) : -1;
-  static const int small_k = getenv("DIF_SMALLK") ? atoi(getenv("DIF_SMALLK")) : 0;
   if (forced >= 0) return (Cout <= 64 && (forced == 0 || forced == 2)) ? forced + 1 : forced;
-  (void)small_k;
   (void)M;
   (void)Cout;
   (void)Kpad;

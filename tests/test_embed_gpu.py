@@ -189,6 +189,45 @@ def test_arcmargin_vs_oracle(cuda):
         head.close()
 
 
+def test_arcmargin_full_size_properties(cuda):
+    """BASELINE configs[2] shape (512 embeddings x 85 742 classes) through size-independent
+    properties: without labels the logits are s * cosine (|logit| <= s, scale invariance in both
+    operands, the row of a class centre fed back as an embedding peaks at s on its own class);
+    with labels only the label column changes, to s*cos(theta + m) or the easy-margin guard; and a
+    sample of columns equals the oracle."""
+    import torch
+    from deep_insight_face.networks.arcmargin import ArcMarginHead
+    B, C = 512, 85_742
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn((C, 512), generator=g)
+    e = torch.randn((B, 512), generator=g)
+    e[:16] = w[1000:1016] * 3.0                          # embeddings that ARE class centres (scaled)
+    lab = torch.randint(0, C, (B,), generator=g)
+    lab[:16] = torch.arange(1000, 1016)
+    head = ArcMarginHead(w.cuda())
+    plain = head.logits(e.cuda())
+    assert plain.shape == (B, C) and bool(torch.isfinite(plain).all())
+    assert float(plain.abs().max()) <= 64.0 + 1e-3
+    assert torch.equal(plain[:16].argmax(1).cpu(), torch.arange(1000, 1016))
+    assert float((plain[:16].max(1).values - 64.0).abs().max()) < 1e-3
+    scaled_e = head.logits((e * 7.5).cuda())
+    assert float((scaled_e - plain).abs().max()) < 2e-3   # cosine does not see the embedding's norm
+    with_m = head.logits(e.cuda(), lab.cuda())
+    diff = (with_m - plain).ne(0)
+    assert int(diff.sum()) <= B and bool(diff[torch.arange(B), lab].sum() >= B - 2)
+    others = diff.clone()
+    others[torch.arange(B), lab] = False
+    assert not bool(others.any())                         # only the label column moves
+    cos = (plain[torch.arange(B), lab] / 64.0).double().clamp(-1, 1).cpu().numpy()
+    th = np.cos(np.pi - 0.5)
+    want = np.where(cos > th, np.cos(np.arccos(cos) + 0.5), cos - np.sin(np.pi - 0.5) * 0.5) * 64.0
+    np.testing.assert_allclose(with_m[torch.arange(B), lab].cpu().numpy(), want, atol=5e-3)
+    cols = np.random.default_rng(1).choice(C, 256, replace=False)
+    ref = nets.arcmargin_logits(e.numpy(), w.numpy()[cols])
+    np.testing.assert_allclose(plain[:, torch.from_numpy(cols).cuda()].cpu().numpy(), ref, atol=64 * TOL)
+    head.close()
+
+
 def test_streamk_fallback_branch(cuda, monkeypatch):
     """The stream-K owner normally adds its partners' partial slabs; if a partner is not
     co-resident it recomputes the missing K range itself.  That branch is rare and
