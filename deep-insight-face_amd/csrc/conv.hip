@@ -558,6 +558,217 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const 
   if (a.trace && tid == 0) a.trace[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
 }
 
+// ------------------------------------------------------------------------------------------
+// Software-pipelined variant for layers with a SHORT K loop and several tiles per resident block
+// (the 1x1 layers of the bottleneck networks, 3x3 layers with 64 input channels).
+//
+// In conv_igemm_kernel a block's life is prologue -> mainloop -> epilogue; with 2..18 K-steps the
+// epilogue (shortcut read + output write, a bandwidth burst when every block reaches it together)
+// is a third of that life and the matrix pipes idle through it.  Here a block is persistent, walks
+// whole tiles of its XCD's share of the tile space round-robin (no tile is ever split, so results
+// do not depend on the schedule; a dynamic queue was tried: on this ISA the atomic's return sits in
+// the same in-order vmcnt queue as the operand loads and delays them), keeps the finished tile's
+// accumulators in a second register set and
+// retires them in eight chunks of two registers DURING the first eight K-steps of the next tile:
+// shortcut loads are issued before a step's MFMAs, scale/shift/activation/add/stores after them.
+// The epilogue works straight from the MFMA D layout (for register r a lane holds one channel of
+// row (r&3) + 8(r>>2) + 4(lane>>5): 32 consecutive channels = 128 contiguous bytes per lane half),
+// so it needs no LDS staging and no barrier, and any output channel count or channel-slice view.
+// Restrictions (checked by the launcher, which otherwise uses conv_igemm_kernel): 64x64 tile, plain
+// spatial output (no padded interior), unit-stride shortcut.
+template <class T, bool PRE, int AM>
+__global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_pipe_kernel(const ConvArgs a) {
+  static_assert(T::WM == 1 && T::WN == 1 && T::WGM == 2 && T::WGN == 2, "pipelined kernel: 64x64 tile only");
+  constexpr int NA = T::NA, NB = T::NB, RP = T::RP;
+  constexpr int BUF = (T::BM + T::BN) * LDS_STRIDE, OFFB = T::BM * LDS_STRIDE;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wr = T::wave_row(), wc = T::wave_col();
+  const int KS = a.Kpad / BK;
+  const int tiles_n = (a.Cout + T::BN - 1) / T::BN;
+  const int ntiles = ((a.M + T::BM - 1) / T::BM) * tiles_n;
+  const int st_off = (tid >> 3) * LDS_STRIDE + (tid & 7) * 4;
+  const int fr_off = (lane & 31) * LDS_STRIDE + 8 * (lane >> 5);
+
+  // this XCD's share of the tile space (hardware block b runs on XCD b % 8: speed only)
+  const int P = gridDim.x, xcd = blockIdx.x & 7;
+  const int chunk_beg = (int)((int64_t)ntiles * xcd / 8), chunk_end = (int)((int64_t)ntiles * (xcd + 1) / 8);
+  const int nblk = (P - xcd + 7) >> 3;                               // blocks on this XCD
+  int tile = chunk_beg + (blockIdx.x >> 3);
+  if (tile >= chunk_end) return;
+
+  using ALoad = typename std::conditional<AM == 1, ConvPwLoader<NA, RP, PRE>, ConvALoader<NA, RP, PRE, 0>>::type;
+  using BLoad = RowLoader<NB, RP>;
+
+  // ---- state of the tile being retired
+  f32x16 accp;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accp[r] = 0.f;
+  const int ecol_l = wc * 32 + (lane & 31);
+  const int erow_l = wr * 32 + 4 * (lane >> 5);
+  int prow0 = 0, pcol = 0;
+  float sc = 1.f, sh = 0.f, sc2 = 1.f, sh2 = 0.f;
+  float rres[2] = {0.f, 0.f};
+
+  // Branch-free on purpose: with branches around the loads the compiler can no longer tell which
+  // vector-memory results are outstanding and drains the queue (vmcnt(0)) in the middle of a K-step,
+  // right after the next step's operand loads were issued.  Buffer accesses with an out-of-range
+  // offset read zero / are dropped, which replaces every lane predicate; a null tensor gets an empty
+  // descriptor.
+  const __amdgpu_buffer_rsrc_t res_rsrc = make_rsrc(a.res, (a.res && !(a.dbg & 2)) ? (uint32_t)((int64_t)a.M * a.Cout * 4) : 0u);
+  const __amdgpu_buffer_rsrc_t y_rsrc = make_rsrc(a.y, (a.y && !(a.dbg & 1)) ? (uint32_t)((int64_t)a.M * a.y_ld * 4) : 0u);
+  const __amdgpu_buffer_rsrc_t y2_rsrc = make_rsrc(a.y2, a.y2 ? (uint32_t)((int64_t)a.M * a.y_ld * 4) : 0u);
+  // No block-uniform conditions inside the steps either (the compiler would branch on them): "no tile
+  // to retire yet" and "column beyond Cout" are folded into row_lim (rows below it are stored), "no
+  // shortcut" into an empty descriptor that reads 0.0, the activation into a per-lane slope for
+  // negative inputs (1 = linear, 0 = ReLU, alpha = PReLU / LeakyReLU).
+  int row_lim = 0;
+  float sl = 1.f, sl2 = 1.f;
+  // chunk J retires registers 2J and 2J+1 of accp
+  auto epi_pre = [&](auto jc) {
+    constexpr int J = decltype(jc)::value;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int r = 2 * J + q;       // compile-time after unrolling
+      const int row = prow0 + (r & 3) + 8 * (r >> 2);
+      const uint32_t off = (uint32_t)(row * a.Cout + pcol) * 4u;
+      rres[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(res_rsrc, row < row_lim ? off : OOB, 0, 0));
+    }
+  };
+  auto epi_post = [&](auto jc) {
+    constexpr int J = decltype(jc)::value;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int r = 2 * J + q;
+      const int row = prow0 + (r & 3) + 8 * (r >> 2);
+      const float v = fmaf(accp[r], sc, sh);
+      const float t = (v >= 0.f ? v : v * sl) + rres[q];
+      const float u = fmaf(t, sc2, sh2);
+      const uint32_t off = (uint32_t)(row * a.y_ld + a.y_coff + pcol) * 4u;
+      const uint32_t o = row < row_lim ? off : OOB;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, t), y_rsrc, o, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, u >= 0.f ? u : u * sl2), y2_rsrc, o, 0, 0);
+    }
+  };
+
+  unsigned long long tr_setup = 0, tr_pro = 0, tr_steps = 0, tr_hand = 0, tr_n = 0;
+  const unsigned long long tr_t0 = __builtin_amdgcn_s_memrealtime();
+  while (true) {
+    const unsigned long long tA = a.trace ? __builtin_amdgcn_s_memrealtime() : 0;
+    int mt, nt;
+    a.fd_tiles_n.divmod(tile, mt, nt);
+    const int m0 = mt * T::BM, n0 = nt * T::BN;
+    ALoad ald(a, m0);
+    BLoad bld(a.w + (int64_t)n0 * a.Kpad, (int64_t)a.Cout - n0, a.Kpad);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    f32x4 ra[NA], rb[NB];
+    auto stage = [&](int buf) {
+      float* wa = smem + buf * BUF + st_off;
+      ald.finish(ra);
+#pragma unroll
+      for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(wa + i * RP * LDS_STRIDE) = ra[i];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(wa + OFFB + i * RP * LDS_STRIDE) = rb[i];
+    };
+    auto mfma_step = [&](int cur) {
+      const float* pa = smem + cur * BUF + (wr * 32) * LDS_STRIDE + fr_off;
+      const float* pb = smem + cur * BUF + OFFB + (wc * 32) * LDS_STRIDE + fr_off;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const f32x4 fa0 = *reinterpret_cast<const f32x4*>(pa + 16 * s2), fa1 = *reinterpret_cast<const f32x4*>(pa + 16 * s2 + 4);
+        const f32x4 fb0 = *reinterpret_cast<const f32x4*>(pb + 16 * s2), fb1 = *reinterpret_cast<const f32x4*>(pb + 16 * s2 + 4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[t], fb0[t], acc, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[t], fb1[t], acc, 0, 0, 0);
+      }
+    };
+    // one K-step; `jc` selects the chunk of the previous tile retired alongside it (8 = none)
+    auto kstep = [&](int ks, auto jc) {
+      constexpr int J = decltype(jc)::value;
+      const bool more = ks + 1 < KS;
+      if (more) {
+        ald.load(ks + 1, ra);
+        bld.load(ks + 1, rb);
+      }
+      if constexpr (J < 8) epi_pre(jc);
+      mfma_step(ks & 1);
+      if constexpr (J < 8) epi_post(jc);
+      if (more) stage((ks & 1) ^ 1);
+      __syncthreads();
+    };
+
+    const unsigned long long tB = a.trace ? __builtin_amdgcn_s_memrealtime() : 0;
+    ald.load(0, ra);
+    bld.load(0, rb);
+    stage(0);
+    __syncthreads();
+    const unsigned long long tC = a.trace ? __builtin_amdgcn_s_memrealtime() : 0;
+    // the first eight steps carry the previous tile's epilogue, unrolled so that its accumulator
+    // registers are addressed statically
+    if (0 < KS) kstep(0, std::integral_constant<int, 0>());
+    if (1 < KS) kstep(1, std::integral_constant<int, 1>());
+    if (2 < KS) kstep(2, std::integral_constant<int, 2>());
+    if (3 < KS) kstep(3, std::integral_constant<int, 3>());
+    if (4 < KS) kstep(4, std::integral_constant<int, 4>());
+    if (5 < KS) kstep(5, std::integral_constant<int, 5>());
+    if (6 < KS) kstep(6, std::integral_constant<int, 6>());
+    if (7 < KS) kstep(7, std::integral_constant<int, 7>());
+    for (int ks = 8; ks < KS; ++ks) kstep(ks, std::integral_constant<int, 8>());
+    // fewer than eight steps: retire the rest of the previous tile now
+    if (KS < 8) {
+      if (KS <= 1) { epi_pre(std::integral_constant<int, 1>()); epi_post(std::integral_constant<int, 1>()); }
+      if (KS <= 2) { epi_pre(std::integral_constant<int, 2>()); epi_post(std::integral_constant<int, 2>()); }
+      if (KS <= 3) { epi_pre(std::integral_constant<int, 3>()); epi_post(std::integral_constant<int, 3>()); }
+      if (KS <= 4) { epi_pre(std::integral_constant<int, 4>()); epi_post(std::integral_constant<int, 4>()); }
+      if (KS <= 5) { epi_pre(std::integral_constant<int, 5>()); epi_post(std::integral_constant<int, 5>()); }
+      if (KS <= 6) { epi_pre(std::integral_constant<int, 6>()); epi_post(std::integral_constant<int, 6>()); }
+      if (KS <= 7) { epi_pre(std::integral_constant<int, 7>()); epi_post(std::integral_constant<int, 7>()); }
+    }
+
+    const unsigned long long tD = a.trace ? __builtin_amdgcn_s_memrealtime() : 0;
+    // hand the finished tile over to the retiring set
+    accp = acc;
+    prow0 = m0 + erow_l;
+    pcol = n0 + ecol_l;
+    if (pcol < a.Cout) {
+      row_lim = a.M;
+      sc = a.scale ? a.scale[pcol] : 1.f;
+      sh = a.shift ? a.shift[pcol] : 0.f;
+      sc2 = a.scale2 ? a.scale2[pcol] : 1.f;
+      sh2 = a.shift2 ? a.shift2[pcol] : 0.f;
+      sl = a.act == ACT_RELU ? 0.f : (a.act == ACT_PRELU ? (a.alpha ? a.alpha[pcol] : 0.f) : 1.f);
+      sl2 = a.act2 == ACT_RELU ? 0.f : (a.act2 == ACT_PRELU ? (a.alpha2 ? a.alpha2[pcol] : 0.f) : 1.f);
+    } else {
+      row_lim = 0;
+    }
+    const int nxt = tile + nblk;                        // static round-robin inside the XCD's chunk
+    if (a.trace) {
+      const unsigned long long tE = __builtin_amdgcn_s_memrealtime();
+      tr_setup += tB - tA; tr_pro += tC - tB; tr_steps += tD - tC; tr_hand += tE - tD; ++tr_n;
+    }
+    if (nxt >= chunk_end) break;
+    tile = nxt;
+  }
+  if (a.trace && tid == 0) {
+    unsigned long long* t = a.trace + (size_t)blockIdx.x * 8;
+    t[0] = tr_setup; t[1] = tr_pro; t[2] = tr_steps; t[3] = tr_hand; t[4] = tr_n; t[5] = tr_t0;
+    t[6] = __builtin_amdgcn_s_memrealtime();
+  }
+  // drain: the last tile has no successor to hide behind
+  epi_pre(std::integral_constant<int, 0>()); epi_post(std::integral_constant<int, 0>());
+  epi_pre(std::integral_constant<int, 1>()); epi_post(std::integral_constant<int, 1>());
+  epi_pre(std::integral_constant<int, 2>()); epi_post(std::integral_constant<int, 2>());
+  epi_pre(std::integral_constant<int, 3>()); epi_post(std::integral_constant<int, 3>());
+  epi_pre(std::integral_constant<int, 4>()); epi_post(std::integral_constant<int, 4>());
+  epi_pre(std::integral_constant<int, 5>()); epi_post(std::integral_constant<int, 5>());
+  epi_pre(std::integral_constant<int, 6>()); epi_post(std::integral_constant<int, 6>());
+  epi_pre(std::integral_constant<int, 7>()); epi_post(std::integral_constant<int, 7>());
+}
+
 static int g_num_cus = 0;
 
 static int num_cus() {
@@ -577,6 +788,50 @@ size_t conv_slab_floats() { return 128 * 128; }
 template <class T, bool PRE, bool DMA, int AM>
 static int launch_conv_pre(const ConvArgs& a, hipStream_t st);
 
+// Short K loop, several whole tiles per resident block, plain output, unit-stride shortcut: the
+// software-pipelined kernel.  Returns 1 when it does not apply (the caller falls through).
+template <class T, bool PRE, int AM>
+static int launch_conv_pipe(const ConvArgs& a, hipStream_t st) {
+  static bool attr_set = false;
+  auto kern = conv_pipe_kernel<T, PRE, AM>;
+  constexpr int lds = T::LDS_BYTES;
+  if (!attr_set) {
+    DIF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  const int64_t tiles = ((a.M + T::BM - 1) / T::BM) * (int64_t)((a.Cout + T::BN - 1) / T::BN);
+  int64_t slots = 4 * (int64_t)num_cus();
+  if (slots > a.sk_max_blocks) slots = a.sk_max_blocks;
+  const int64_t P = tiles < slots ? tiles : slots;
+  ConvArgs b = a;
+  b.fd_howo = make_fastdiv(a.Ho * a.Wo);
+  b.fd_wo = make_fastdiv(a.Wo);
+  b.fd_cin = make_fastdiv(a.Cin);
+  b.fd_kw = make_fastdiv(a.KW);
+  b.fd_ks = make_fastdiv(a.Kpad / BK);
+  b.fd_taps = make_fastdiv(a.KH * a.KW);
+  b.fd_tiles_n = make_fastdiv((a.Cout + T::BN - 1) / T::BN);
+  static const int dbg = getenv("DIF_PIPE_DBG") ? atoi(getenv("DIF_PIPE_DBG")) : 0;
+  b.dbg = dbg;
+  hipLaunchKernelGGL(kern, dim3((unsigned)P), dim3(T::NT), lds, st, b);
+  DIF_HIP(hipGetLastError());
+  return 0;
+}
+
+static bool pipe_applies(const ConvArgs& a, int64_t tiles, int KS, int64_t slots) {
+  const char* e = getenv("DIF_PIPE");     // read per launch: tests compare both paths inside one process
+  const int use_pipe = e ? atoi(e) : 1;
+  static const int sk_min_ks = getenv("DIF_SK_MIN_KS") ? atoi(getenv("DIF_SK_MIN_KS")) : 32;
+  if (!use_pipe) return false;
+  if (KS >= sk_min_ks && tiles < 8 * slots) return false;           // long K, few tiles: stream-K's case
+  if (tiles < slots + slots / 2) return false;                        // fewer than ~1.5 tiles per block: nothing to overlap
+  if (KS < 3 && a.res) return false;   // two K-steps cannot carry a shortcut epilogue: measured 8-13 % slower
+  if (!(a.y_H == a.Ho && a.y_W == a.Wo && a.y_oy == 0 && a.y_ox == 0)) return false;
+  if (a.res && (a.res_stride != 1 || a.res_H != a.Ho || a.res_W != a.Wo)) return false;
+  if ((int64_t)a.M * (a.y_ld > a.Cout ? a.y_ld : a.Cout) * 4 >= 0xFFFFFFF0LL) return false;   // 32-bit buffer offsets
+  return true;
+}
+
 template <class T>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
   // LDS-DMA operand staging is +1..5 % on the plain GEMM microbenchmark but -1.2 % inside this
@@ -591,6 +846,14 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
   // run-time-selected path on IResNet-100 -- hipcc schedules the loop differently -- so the
   // multi-tap layers stay on the general loader)
   if constexpr (kDefaultTile) {
+    const int64_t tiles = ((a.M + T::BM - 1) / T::BM) * (int64_t)((a.Cout + T::BN - 1) / T::BN);
+    int64_t slots = 4 * (int64_t)num_cus();
+    if (slots > a.sk_max_blocks) slots = a.sk_max_blocks;
+    if (!use_dma && a.Cin % 4 == 0 && pipe_applies(a, tiles, a.Kpad / BK, slots)) {
+      if (pw && a.pre_scale) return launch_conv_pipe<T, true, 1>(a, st);
+      if (pw) return launch_conv_pipe<T, false, 1>(a, st);
+      if (!a.pre_scale) return launch_conv_pipe<T, false, 0>(a, st);
+    }
     if (pw && a.pre_scale) return launch_conv_pre<T, true, false, 1>(a, st);
     if (pw) return launch_conv_pre<T, false, false, 1>(a, st);
   }

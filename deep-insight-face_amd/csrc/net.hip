@@ -827,6 +827,7 @@ int Net::finalize(int mb) {
     L.sk_flag = static_cast<unsigned*>(d);
     DIF_HIP(hipMemset(L.sk_flag, 0, (size_t)sk_max_blocks * sizeof(unsigned)));
     L.sk_epoch = 0;
+
     L.bufs.assign(buf_elems.size(), nullptr);
     for (size_t b = 0; b < buf_elems.size(); ++b) {
       float* f = nullptr;

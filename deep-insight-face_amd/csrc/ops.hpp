@@ -76,6 +76,7 @@ struct ConvArgs {
   unsigned sk_epoch;
   int sk_max_blocks;
   int sk_spin_limit;    // polls before the owner computes a missing K range itself; < 0: always (test hook)
+  int dbg;              // development aid: bit 0 drops the pipelined kernel's stores, bit 1 its shortcut loads
   // development aid (tools/ubench/conv_trace.hip), null in the library: 4 x u64 per hardware block =
   // s_memrealtime (100 MHz) at entry / after the first mainloop / at exit, and the HW_ID register
   unsigned long long* trace;

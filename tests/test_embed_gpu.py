@@ -228,6 +228,37 @@ def test_arcmargin_full_size_properties(cuda):
     head.close()
 
 
+def test_pipelined_kernel_equals_plain_kernel(cuda, monkeypatch):
+    """Layers with a short K loop and several tiles per resident block run on the software-pipelined
+    kernel (conv_pipe_kernel: persistent blocks, the previous tile's epilogue retired inside the next
+    tile's K-steps, stores straight from the MFMA layout).  Same arithmetic per output element as
+    conv_igemm_kernel, so the two must agree to float32 rounding of the activation's zero sign:
+    ResNet50V2 at batch 192 (pre-activation, shortcuts, ragged last tile), IResNet-50 (PReLU, 3x3
+    layers with 64 input channels) and YOLOv3-face (LeakyReLU slopes, shortcut adds, 18-channel heads,
+    concat views) are run both ways in one process."""
+    import torch
+    from deep_insight_face.networks.triplet import DifEmbedder
+    rng = np.random.default_rng(21)
+    cases = [('resnet', 'v2', 512, (112, 112, 3), 192), ('iresnet50', 'v2', 512, (112, 112, 3), 96),
+             ('yolov3', 'v3', 1, (416, 416, 3), 2)]
+    for arch, head, emd, shape, n in cases:
+        x = torch.from_numpy(rng.integers(0, 256, (n,) + shape, dtype=np.uint8)).cuda()
+        m = DifEmbedder(arch, head, emd, shape, max_batch=n).init_synthetic(5)
+        m.set_input_transform(scale=1 / 255.)
+        monkeypatch.setenv('DIF_PIPE', '1')
+        a = m.embed(x)
+        a2 = m.embed(x)
+        monkeypatch.setenv('DIF_PIPE', '0')
+        b = m.embed(x)
+        monkeypatch.delenv('DIF_PIPE')
+        a, a2, b = [t if isinstance(t, list) else [t] for t in (a, a2, b)]
+        for ta, ta2, tb in zip(a, a2, b):
+            assert torch.equal(ta, ta2)                                   # deterministic
+            scale = float(tb.abs().max())
+            assert float((ta - tb).abs().max()) <= 2e-6 * max(scale, 1.0), arch
+        m.close()
+
+
 def test_streamk_fallback_branch(cuda, monkeypatch):
     """The stream-K owner normally adds its partners' partial slabs; if a partner is not
     co-resident it recomputes the missing K range itself.  That branch is rare and

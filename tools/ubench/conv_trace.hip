@@ -34,7 +34,7 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&sc, hv.size() * 4)); CK(hipMalloc(&sh, hv.size() * 4));
   CK(hipMalloc(&slab, (size_t)maxb * dif::conv_slab_floats() * 4)); CK(hipMalloc(&flag, maxb * 4));
   const int64_t max_tiles = std::max<int64_t>(((M + 63) / 64) * ((Cout + 63) / 64), maxb);
-  CK(hipMalloc(&trace, (size_t)max_tiles * 32));
+  CK(hipMalloc(&trace, (size_t)max_tiles * 64));
   CK(hipMemcpy(x, hx.data(), nx * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(w, hw.data(), nw * 4, hipMemcpyHostToDevice));
   CK(hipMemset(r, 0, ny * 4)); CK(hipMemset(flag, 0, maxb * 4));
@@ -49,6 +49,7 @@ int main(int argc, char** argv) {
   a.res_H = Ho; a.res_W = Wo; a.res_stride = 1;
   a.y_ld = Cout; a.y_H = Ho; a.y_W = Wo;
   a.sk_slab = slab; a.sk_flag = flag; a.sk_max_blocks = maxb; a.sk_spin_limit = 1 << 20;
+
   unsigned epoch = 0;
   hipStream_t st = nullptr;
   for (int i = 0; i < 5; ++i) { a.sk_epoch = ++epoch; if (dif::conv_run(a, -1, st)) { printf("conv_run failed\n"); return 1; } }
@@ -65,16 +66,34 @@ int main(int argc, char** argv) {
   const double flops = 2.0 * M * Cout * Kdim;
   printf("M=%lld N=%d K=%d (KS=%d)  %.4f ms  %.1f TFLOP/s  ideal@144TF %.1f us\n", (long long)M, Cout, Kdim, Kpad / 32,
          ms, flops / ms / 1e9, flops / 144e12 * 1e6);
+  {
+    std::vector<float> hy(ny);
+    CK(hipMemcpy(hy.data(), y, ny * 4, hipMemcpyDeviceToHost));
+    double cs = 0, ca = 0;
+    for (size_t i = 0; i < ny; ++i) { cs += hy[i]; ca += hy[i] * (double)((i % 97) + 1); }
+    printf("checksum %.9g %.9g\n", cs, ca);
+  }
   // traced run
-  CK(hipMemset(trace, 0, (size_t)max_tiles * 32));
+  CK(hipMemset(trace, 0, (size_t)max_tiles * 64));
   a.trace = trace; a.sk_epoch = ++epoch;
   dif::conv_run(a, -1, st);
   CK(hipDeviceSynchronize());
-  std::vector<unsigned long long> t((size_t)max_tiles * 4);
+  std::vector<unsigned long long> t((size_t)max_tiles * 8);
   CK(hipMemcpy(t.data(), trace, t.size() * 8, hipMemcpyDeviceToHost));
+  if (getenv("PIPE_TRACE")) {      // layout written by conv_pipe_kernel: 8 x u64 per block
+    double su = 0, pr = 0, stp = 0, hd = 0, n = 0, life = 0; int nb2 = 0;
+    for (int b = 0; b < maxb; ++b) if (t[(size_t)b * 8 + 4]) {
+      su += t[b * 8] * 0.01; pr += t[b * 8 + 1] * 0.01; stp += t[b * 8 + 2] * 0.01; hd += t[b * 8 + 3] * 0.01; n += t[b * 8 + 4];
+      life += (t[b * 8 + 6] - t[b * 8 + 5]) * 0.01; ++nb2;
+    }
+    printf("pipe trace: %d blocks, %.1f tiles/block; per tile: setup %.2f us, prologue (first loads -> LDS) %.2f us, K-steps %.2f us, hand-over %.2f us; block life %.1f us\n",
+           nb2, n / nb2, su / n, pr / n, stp / n, hd / n, life / nb2);
+    return 0;
+  }
   int64_t nb = 0;
   unsigned long long tmin = ~0ull, tmax = 0;
   for (int64_t b = 0; b < max_tiles; ++b) if (t[b * 4]) { ++nb; tmin = std::min(tmin, t[b * 4]); tmax = std::max(tmax, t[b * 4 + 2]); }
+  if (nb == 0) { printf("(no block trace: the pipelined kernel does not stamp)\n"); return 0; }
   double ml = 0, ep = 0;
   std::vector<double> mls, eps, starts;
   std::map<unsigned long long, int> per_cu;
