@@ -284,7 +284,7 @@ def main():
                           {'detect+crop': float(np.mean([ev[i][0].elapsed_time(det_ms[i]) for i in range(args.steps)])),
                            'detect+crop+embed': embed_ms, 'match': match_ms}),
             'roofline': {
-                'bound': 'mfma', 'kernel': 'conv_igemm_kernel (f32 MFMA implicit-GEMM conv; one launch group = the '
+                'bound': 'mfma', 'kernel': 'conv_igemm_kernel + conv_pipe_kernel (f32 MFMA implicit-GEMM conv; one launch group = the '
                                            '%d conv launches of one %s forward at batch %d)'
                                            % (sum(1 for _, k, _, _ in prof if k.startswith('conv_igemm')), arch, batch),
                 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',

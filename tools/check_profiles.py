@@ -41,7 +41,7 @@ def main():
             subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', 'pmc_traffic.py'), pf, pw, '5'], stdout=fh)
         conv_ns, conv_calls = 0.0, 0
         for r in csv.DictReader(open(ks)):
-            if 'conv_igemm_kernel' in r['Name']:
+            if 'conv_igemm_kernel' in r['Name'] or 'conv_pipe_kernel' in r['Name']:
                 conv_ns += float(r['TotalDurationNs'])
                 conv_calls += int(r['Calls'])
         bench = json.load(open(os.path.join(OUT, 'bench_%s.json' % w)))
