@@ -448,13 +448,12 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const 
   const int I = tiles_m * tiles_n * KS;                       // < 2^31 (checked by conv_run)
   const int beg = (int)((int64_t)I * p / P), end = (int)((int64_t)I * (p + 1) / P);
 
-  if (a.trace && tid == 0) {
-    a.trace[blockIdx.x * 4] = __builtin_amdgcn_s_memrealtime();
-    a.trace[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 4 /* HW_ID, 32 bits */) |
-                                  ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20 /* XCC_ID */) << 32);
-  }
+  // development aid: time per phase, summed over the block's tiles (100 MHz ticks)
+  unsigned long long tr_main = 0, tr_fix = 0, tr_epi = 0, tr_steps = 0, tr_tiles = 0;
+  const unsigned long long tr_t0 = a.trace ? __builtin_amdgcn_s_memrealtime() : 0;
   int it = beg;
   while (it < end) {
+    const unsigned long long tA = a.trace ? __builtin_amdgcn_s_memrealtime() : 0;
     int tile, kb, mt, nt;
     a.fd_ks.divmod(it, tile, kb);
     const int left = end - it;
@@ -483,7 +482,8 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const 
         });
     };
     run(kb, ke, whole);
-    if (a.trace && tid == 0 && it == beg) a.trace[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long tB = a.trace ? __builtin_amdgcn_s_memrealtime() : 0;
+    unsigned long long tC = tB;
 
     if (kb != 0) {
       // not the owner of this tile: publish the partial accumulators (fragment order, 16 B per lane)
@@ -551,11 +551,24 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const 
         }
         kdone = q_ke;
       }
+      if (a.trace) tC = __builtin_amdgcn_s_memrealtime();
       conv_epilogue<T>(a, acc, m0, n0, smem, er, whole);
+    }
+    if (a.trace) {
+      const unsigned long long tD = __builtin_amdgcn_s_memrealtime();
+      tr_main += tB - tA;
+      if (kb != 0) tr_fix += tD - tB; else { tr_fix += tC - tB; tr_epi += tD - tC; }
+      tr_steps += ke - kb;
+      ++tr_tiles;
     }
     it += ke - kb;
   }
-  if (a.trace && tid == 0) a.trace[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+  if (a.trace && tid == 0) {
+    unsigned long long* t = a.trace + (size_t)blockIdx.x * 8;
+    t[0] = tr_main; t[1] = tr_fix; t[2] = tr_epi; t[3] = tr_steps; t[4] = tr_tiles; t[5] = tr_t0;
+    t[6] = __builtin_amdgcn_s_memrealtime();
+    t[7] = 1;   // 1 = conv_igemm_kernel record, 2 = conv_pipe_kernel record
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -757,6 +770,7 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_pipe_kernel(const C
     unsigned long long* t = a.trace + (size_t)blockIdx.x * 8;
     t[0] = tr_setup; t[1] = tr_pro; t[2] = tr_steps; t[3] = tr_hand; t[4] = tr_n; t[5] = tr_t0;
     t[6] = __builtin_amdgcn_s_memrealtime();
+    t[7] = 2;
   }
   // drain: the last tile has no successor to hide behind
   epi_pre(std::integral_constant<int, 0>()); epi_post(std::integral_constant<int, 0>());

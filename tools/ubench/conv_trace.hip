@@ -80,55 +80,24 @@ int main(int argc, char** argv) {
   CK(hipDeviceSynchronize());
   std::vector<unsigned long long> t((size_t)max_tiles * 8);
   CK(hipMemcpy(t.data(), trace, t.size() * 8, hipMemcpyDeviceToHost));
-  if (getenv("PIPE_TRACE")) {      // layout written by conv_pipe_kernel: 8 x u64 per block
-    double su = 0, pr = 0, stp = 0, hd = 0, n = 0, life = 0; int nb2 = 0;
-    for (int b = 0; b < maxb; ++b) if (t[(size_t)b * 8 + 4]) {
-      su += t[b * 8] * 0.01; pr += t[b * 8 + 1] * 0.01; stp += t[b * 8 + 2] * 0.01; hd += t[b * 8 + 3] * 0.01; n += t[b * 8 + 4];
-      life += (t[b * 8 + 6] - t[b * 8 + 5]) * 0.01; ++nb2;
-    }
-    printf("pipe trace: %d blocks, %.1f tiles/block; per tile: setup %.2f us, prologue (first loads -> LDS) %.2f us, K-steps %.2f us, hand-over %.2f us; block life %.1f us\n",
-           nb2, n / nb2, su / n, pr / n, stp / n, hd / n, life / nb2);
-    return 0;
-  }
-  int64_t nb = 0;
+  double v[5] = {0, 0, 0, 0, 0}, life = 0;
   unsigned long long tmin = ~0ull, tmax = 0;
-  for (int64_t b = 0; b < max_tiles; ++b) if (t[b * 4]) { ++nb; tmin = std::min(tmin, t[b * 4]); tmax = std::max(tmax, t[b * 4 + 2]); }
-  if (nb == 0) { printf("(no block trace: the pipelined kernel does not stamp)\n"); return 0; }
-  double ml = 0, ep = 0;
-  std::vector<double> mls, eps, starts;
-  std::map<unsigned long long, int> per_cu;
-  for (int64_t b = 0; b < max_tiles; ++b) if (t[b * 4]) {
-    mls.push_back((t[b * 4 + 1] - t[b * 4]) * 0.01); eps.push_back((t[b * 4 + 2] - t[b * 4 + 1]) * 0.01);
-    starts.push_back((t[b * 4] - tmin) * 0.01);
-    ml += mls.back(); ep += eps.back();
-    const unsigned hw = (unsigned)t[b * 4 + 3];
-    const unsigned long long key = ((t[b * 4 + 3] >> 32) << 16) | (((hw >> 13) & 7) << 8) | ((hw >> 8) & 15);   // xcc, se, cu
-    per_cu[key]++;
+  int nb = 0, kind = 0;
+  for (int64_t b = 0; b < max_tiles; ++b) if (t[(size_t)b * 8 + 7]) {
+    kind = (int)t[b * 8 + 7];
+    for (int i = 0; i < 5; ++i) v[i] += (double)t[b * 8 + i];
+    life += (t[b * 8 + 6] - t[b * 8 + 5]) * 0.01;
+    tmin = std::min(tmin, t[b * 8 + 5]); tmax = std::max(tmax, t[b * 8 + 6]);
+    ++nb;
   }
-  if (getenv("SHOW_MAP")) {
-    for (int64_t b = 0; b < std::min<int64_t>(max_tiles, 160); ++b) if (t[b * 4]) {
-      const unsigned hw = (unsigned)t[b * 4 + 3];
-      printf("  block %4lld: xcc %llu se %u sh %u cu %2u simd %u wave %u  start %.2f us\n", (long long)b, t[b * 4 + 3] >> 32,
-             (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 15, (hw >> 4) & 3, hw & 15, (t[b * 4] - tmin) * 0.01);
-    }
-  }
-  std::sort(mls.begin(), mls.end()); std::sort(eps.begin(), eps.end());
-  printf("blocks %lld on %zu CUs; span %.1f us; first-mainloop mean %.2f us (p10 %.2f p50 %.2f p90 %.2f); rest-of-block mean %.2f us (p10 %.2f p50 %.2f p90 %.2f)\n",
-         (long long)nb, per_cu.size(), (tmax - tmin) * 0.01, ml / nb, mls[nb / 10], mls[nb / 2], mls[nb * 9 / 10], ep / nb,
-         eps[nb / 10], eps[nb / 2], eps[nb * 9 / 10]);
-  // concurrency over time: blocks alive in 2 us buckets, and how many are in their mainloop
-  const double span = (tmax - tmin) * 0.01;
-  const int nbk = (int)(span / 2.0) + 1;
-  std::vector<double> alive(nbk, 0), inml(nbk, 0);
-  for (int64_t b = 0; b < max_tiles; ++b) if (t[b * 4]) {
-    const double s = (t[b * 4] - tmin) * 0.01, m = (t[b * 4 + 1] - tmin) * 0.01, e = (t[b * 4 + 2] - tmin) * 0.01;
-    for (int k = 0; k < nbk; ++k) {
-      const double lo = k * 2.0, hi = lo + 2.0;
-      alive[k] += std::max(0.0, std::min(hi, e) - std::max(lo, s)) / 2.0;
-      inml[k] += std::max(0.0, std::min(hi, m) - std::max(lo, s)) / 2.0;
-    }
-  }
-  printf("t(us): alive / in-first-mainloop (avg blocks)\n");
-  for (int k = 0; k < nbk; ++k) printf("  %5.0f: %7.1f %7.1f\n", k * 2.0, alive[k], inml[k]);
+  if (!nb) { printf("(no trace records)\n"); return 0; }
+  if (kind == 2)
+    printf("pipelined kernel: %d blocks, %.2f tiles/block, span %.1f us, mean block life %.1f us; per tile: set-up %.2f us, first loads -> LDS %.2f us, "
+           "K-steps %.2f us, hand-over %.2f us\n", nb, v[4] / nb, (tmax - tmin) * 0.01, life / nb, v[0] * 0.01 / v[4], v[1] * 0.01 / v[4],
+           v[2] * 0.01 / v[4], v[3] * 0.01 / v[4]);
+  else
+    printf("plain kernel: %d blocks, %.2f (part-)tiles/block, %.1f K-steps/block, span %.1f us, mean block life %.1f us; per block: "
+           "mainloops %.1f us (%.2f us/K-step incl. prologues), publish/collect partials %.1f us, epilogues %.1f us\n", nb, v[4] / nb, v[3] / nb,
+           (tmax - tmin) * 0.01, life / nb, v[0] * 0.01 / nb, v[0] * 0.01 / v[3], v[1] * 0.01 / nb, v[2] * 0.01 / nb);
   return 0;
 }
