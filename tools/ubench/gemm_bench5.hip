@@ -1,0 +1,125 @@
+// Microbenchmark 5: where does the K loop of the 64x64 / four-blocks-per-CU mainloop lose its 20 %?
+// Same loop as gemm_core.hpp's gemm_mainloop with pieces switched off (results are then wrong on
+// purpose; only the time matters):  bit 0 = no barrier, bit 1 = no global loads, bit 2 = no LDS
+// fragment reads, bit 3 = no LDS staging writes.   usage: gemm_bench5 [M N K]
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include "gemm_core.hpp"
+using namespace dif;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
+
+template <int V>
+__global__ __launch_bounds__(256, 4) void k(const float* A, const float* B, float* C, int M, int N, int K) {
+  using T = Tile<1, 1>;
+  constexpr int NA = T::NA, NB = T::NB, RP = T::RP;
+  constexpr int BUF = (64 + 64) * LDS_STRIDE, OFFB = 64 * LDS_STRIDE;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wr = T::wave_row(), wc = T::wave_col();
+  const int tiles_n = N / 64;
+  const int KS = K / 32;
+  const int st_off = (tid >> 3) * LDS_STRIDE + (tid & 7) * 4;
+  const int fr_off = (lane & 31) * LDS_STRIDE + 8 * (lane >> 5);
+  for (int tile = blockIdx.x; tile < (M / 64) * tiles_n; tile += gridDim.x) {
+    const int m0 = (tile / tiles_n) * 64, n0 = (tile % tiles_n) * 64;
+    RowLoader<NA, RP> al(A + (int64_t)m0 * K, M - m0, K);
+    RowLoader<NB, RP> bl(B + (int64_t)n0 * K, N - n0, K);
+    f32x16 acc;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    f32x4 ra[NA], rb[NB];
+    al.load(0, ra); bl.load(0, rb);
+    for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(lds + st_off + i * RP * LDS_STRIDE) = ra[i];
+    for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(lds + OFFB + st_off + i * RP * LDS_STRIDE) = rb[i];
+    __syncthreads();
+    f32x4 fa0 = {1.f, 2.f, 3.f, 4.f}, fa1 = fa0, fb0 = fa0, fb1 = fa0;
+    for (int ks = 0; ks < KS; ++ks) {
+      const int cur = ks & 1;
+      const bool more = ks + 1 < KS;
+      if (!(V & 2) && more) { al.load(ks + 1, ra); bl.load(ks + 1, rb); }
+      const float* pa = lds + cur * BUF + (wr * 32) * LDS_STRIDE + fr_off;
+      const float* pb = lds + cur * BUF + OFFB + (wc * 32) * LDS_STRIDE + fr_off;
+      if (V & 16) {
+        // all eight fragment reads of the step up front: the second half lands while the first 8 MFMAs run
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(pa), a1 = *reinterpret_cast<const f32x4*>(pa + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(pb), b1 = *reinterpret_cast<const f32x4*>(pb + 4);
+        const f32x4 a2 = *reinterpret_cast<const f32x4*>(pa + 16), a3 = *reinterpret_cast<const f32x4*>(pa + 20);
+        const f32x4 b2 = *reinterpret_cast<const f32x4*>(pb + 16), b3 = *reinterpret_cast<const f32x4*>(pb + 20);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b0[t], acc, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b1[t], acc, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[t], b2[t], acc, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3[t], b3[t], acc, 0, 0, 0);
+      } else
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        if (!(V & 4)) {
+          fa0 = *reinterpret_cast<const f32x4*>(pa + 16 * s); fa1 = *reinterpret_cast<const f32x4*>(pa + 16 * s + 4);
+          fb0 = *reinterpret_cast<const f32x4*>(pb + 16 * s); fb1 = *reinterpret_cast<const f32x4*>(pb + 16 * s + 4);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[t], fb0[t], acc, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[t], fb1[t], acc, 0, 0, 0);
+      }
+      if (!(V & 8) && more) {
+        float* wa = lds + (cur ^ 1) * BUF + st_off;
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(wa + i * RP * LDS_STRIDE) = ra[i];
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(wa + OFFB + i * RP * LDS_STRIDE) = rb[i];
+      }
+      if (!(V & 1)) __syncthreads();
+    }
+    // minimal epilogue so that nothing is optimised away
+    float sacc = 0.f;
+    for (int r = 0; r < 16; ++r) sacc += acc[r];
+    if (V & 2) sacc += ra[0][0] + rb[0][0];
+    C[(int64_t)tile * 256 + tid] = sacc;
+    __syncthreads();
+  }
+}
+
+template <int V>
+static void run(const char* name, const float* A, const float* B, float* C, int M, int N, int K) {
+  auto kern = k<V>;
+  const int lds = Tile<1, 1>::LDS_BYTES;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(1024), dim3(256), lds, 0, A, B, C, M, N, K);
+  CK(hipEventRecord(e0));
+  const int reps = 10;
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(1024), dim3(256), lds, 0, A, B, C, M, N, K);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= reps;
+  printf("%-46s %8.3f ms  %6.1f TFLOP/s (%.1f %% of 157.3)\n", name, ms, 2.0 * M * N * K / ms / 1e9, 2.0 * M * N * K / ms / 1e9 / 1.573);
+}
+
+int main(int argc, char** argv) {
+  int M = argc > 3 ? atoi(argv[1]) : 16384, N = argc > 3 ? atoi(argv[2]) : 4096, K = argc > 3 ? atoi(argv[3]) : 2304;
+  float *A, *B, *C;
+  CK(hipMalloc(&A, (size_t)M * K * 4)); CK(hipMalloc(&B, (size_t)N * K * 4)); CK(hipMalloc(&C, (size_t)(M / 64) * (N / 64) * 256 * 4));
+  std::vector<float> h((size_t)M * K);
+  for (auto& v : h) v = (rand() % 200 - 100) * 0.01f;
+  CK(hipMemcpy(A, h.data(), (size_t)M * K * 4, hipMemcpyHostToDevice));
+  h.resize((size_t)N * K);
+  CK(hipMemcpy(B, h.data(), (size_t)N * K * 4, hipMemcpyHostToDevice));
+  printf("M=%d N=%d K=%d, 64x64 tile, 1024 persistent blocks (4 per CU)\n", M, N, K);
+  run<0>("full loop", A, B, C, M, N, K);
+  run<1>("no barrier", A, B, C, M, N, K);
+  run<2>("no global loads", A, B, C, M, N, K);
+  run<4>("no LDS fragment reads", A, B, C, M, N, K);
+  run<8>("no LDS staging writes", A, B, C, M, N, K);
+  run<2 | 8>("no global loads, no staging writes", A, B, C, M, N, K);
+  run<1 | 2 | 8>("no barrier, no loads, no staging", A, B, C, M, N, K);
+  run<1 | 2 | 4 | 8>("MFMA only", A, B, C, M, N, K);
+  run<16>("full loop, fragment reads up front", A, B, C, M, N, K);
+  run<16 | 2 | 8>("frag up front, no loads/staging", A, B, C, M, N, K);
+  return 0;
+}
