@@ -306,6 +306,7 @@ struct ConvADmaLoader {
 __device__ __forceinline__ float apply_act(float v, int act, float alpha) {
   if (act == ACT_RELU) return fmaxf(v, 0.f);
   if (act == ACT_PRELU) return v >= 0.f ? v : v * alpha;
+  if (act == ACT_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
   return v;
 }
 
@@ -839,6 +840,7 @@ static bool pipe_applies(const ConvArgs& a, int64_t tiles, int KS, int64_t slots
   if (!use_pipe) return false;
   if (KS >= sk_min_ks && tiles < 8 * slots) return false;           // long K, few tiles: stream-K's case
   if (tiles < slots + slots / 2) return false;                        // fewer than ~1.5 tiles per block: nothing to overlap
+  if (a.act == ACT_RELU6 || a.act2 == ACT_RELU6) return false;        // its epilogue knows slopes, not clamps
   if (KS < 3 && a.res) return false;   // two K-steps cannot carry a shortcut epilogue: measured 8-13 % slower
   if (!(a.y_H == a.Ho && a.y_W == a.Wo && a.y_oy == 0 && a.y_ox == 0)) return false;
   if (a.res && (a.res_stride != 1 || a.res_H != a.Ho || a.res_W != a.Wo)) return false;

@@ -60,6 +60,63 @@ int input_convert_run(const InputArgs& a, hipStream_t st) {
   return 0;
 }
 
+// ---------------------------------------------------------------- depthwise KxK convolution
+// MobileNetV2's DepthwiseConv2D(3, stride 1 'same' | stride 2 after ZeroPadding2D(correct_pad)) + BN +
+// ReLU6, one thread per (pixel, 4 channels): 9 float4 loads + 9 weight float4 (L1/L2-resident) per
+// output float4 -- memory-bound, nothing for the matrix pipe here.
+__global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                                     float* __restrict__ y, int N, int H, int W, int C, int K,
+                                                     int stride, int pad_t, int pad_l, int Ho, int Wo, int act) {
+  const int C4 = C / 4;
+  const int64_t total = (int64_t)N * Ho * Wo * C4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
+    int64_t p = i / C4;
+    const int wo = (int)(p % Wo);
+    p /= Wo;
+    const int ho = (int)(p % Ho);
+    const int64_t n = p / Ho;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int kh = 0; kh < K; ++kh) {
+      const int hi = ho * stride - pad_t + kh;
+      if ((unsigned)hi >= (unsigned)H) continue;
+      for (int kw = 0; kw < K; ++kw) {
+        const int wi = wo * stride - pad_l + kw;
+        if ((unsigned)wi >= (unsigned)W) continue;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((n * H + hi) * W + wi) * C + c4 * 4);
+        const f32x4 k = *reinterpret_cast<const f32x4*>(w + (int64_t)(kh * K + kw) * C + c4 * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = fmaf(v[j], k[j], acc[j]);
+      }
+    }
+    const f32x4 sc = scale ? *reinterpret_cast<const f32x4*>(scale + c4 * 4) : f32x4{1.f, 1.f, 1.f, 1.f};
+    const f32x4 sh = shift ? *reinterpret_cast<const f32x4*>(shift + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float t = fmaf(acc[j], sc[j], sh[j]);
+      if (act == ACT_RELU) t = fmaxf(t, 0.f);
+      else if (act == ACT_RELU6) t = fminf(fmaxf(t, 0.f), 6.f);
+      o[j] = t;
+    }
+    *reinterpret_cast<f32x4*>(y + i * 4) = o;
+  }
+}
+
+int dwconv_run(const float* x, const float* w, const float* scale, const float* shift, float* y, int N, int H, int W,
+               int C, int K, int stride, int pad_t, int pad_l, int Ho, int Wo, int act, hipStream_t st) {
+  if (C % 4 != 0) return set_error("dwconv: C must be a multiple of 4 (got %d)", C);
+  const int64_t total = (int64_t)N * Ho * Wo * (C / 4);
+  if (total == 0) return 0;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(dwconv_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, w, scale, shift, y, N, H, W, C, K, stride,
+                     pad_t, pad_l, Ho, Wo, act);
+  DIF_HIP(hipGetLastError());
+  return 0;
+}
+
 // ---------------------------------------------------------------- pooling (max / L2 / average)
 __global__ __launch_bounds__(256) void maxpool_kernel(const PoolArgs a) {
   const int C4 = a.C / 4;

@@ -241,7 +241,12 @@ int Net::build_resnet50v2() {
     }
   }
   (void)cin;
-  const int feat = pre;   // relu(post_bn(.)): [H/32, W/32, 2048]
+  return build_heads(pre);   // pre = relu(post_bn(.)): [H/32, W/32, 2048]
+}
+
+// The embedding heads of bottleneck_network (triplet.py:102-141) on any backbone's feature map.
+int Net::build_heads(int feat) {
+  const BNRef none;
   const TensorDesc fd = tensors[feat];
   if (head == "v3") {
     output_tensor = feat;
@@ -317,6 +322,100 @@ int Net::build_resnet50v2() {
     return 0;
   }
   return set_error("unknown head '%s' (v1, v2, v3)", head.c_str());
+}
+
+// ----------------------------------------------------------------------------- VGG16 / MobileNetV2
+// The other two backbones bottleneck_network accepts (triplet.py:77,87-93): keras.applications
+// VGG16 and MobileNetV2 (alpha 1.0), include_top=False.  Third-party definitions, restated from their
+// public layer tables like ResNet50V2; same parameter names as Keras.
+void Net::add_input() {
+  input_tensor = T(in_h, in_w, 4);
+  Op in;
+  in.kind = OP_INPUT;
+  in.name = "input";
+  in.y = input_tensor;
+  ops.push_back(in);
+}
+
+int Net::build_vgg16() {
+  const BNRef none;
+  add_input();
+  static const int cfg[5][2] = {{64, 2}, {128, 2}, {256, 3}, {512, 3}, {512, 3}};
+  int x = input_tensor;
+  for (int b = 0; b < 5; ++b) {
+    for (int c = 1; c <= cfg[b][1]; ++c) {
+      char nm[32];
+      snprintf(nm, sizeof(nm), "block%d_conv%d", b + 1, c);
+      x = conv(nm, x, 3, 3, 1, 1, cfg[b][0], true, none, ACT_RELU, -1, -1, 1, true, none, ACT_NONE, nullptr);
+    }
+    char nm[32];
+    snprintf(nm, sizeof(nm), "block%d_pool", b + 1);
+    x = pool(nm, x, 2, 2, 0, POOL_MAX, 0);
+    if (tensors[x].H < 1 || tensors[x].W < 1) return set_error("vgg16: input %dx%d is too small", in_h, in_w);
+  }
+  return build_heads(x);
+}
+
+int Net::build_mobilenetv2() {
+  const BNRef none;
+  add_input();
+  const float eps = 1e-3f;    // keras MobileNetV2: BatchNormalization(epsilon=1e-3, momentum=0.999)
+  // keras correct_pad for a 3x3 stride-2 layer: ((1 - H%2 ... )) -> even size: 0 before / 1 after; odd: 1 / 1
+  auto pad_tl = [&](int size) { return size % 2 == 0 ? 0 : 1; };
+  auto dw = [&](const std::string& name, int x, int stride) {
+    const TensorDesc xd = tensors[x];
+    Op d;
+    d.kind = OP_DWCONV;
+    d.name = name;
+    d.x = x;
+    d.KH = d.KW = 3;
+    d.stride = stride;
+    d.Cin = d.Cout = xd.C;
+    int Ho, Wo;
+    if (stride == 1) {
+      d.pad_t = d.pad_l = 1;      // 'same'
+      Ho = xd.H;
+      Wo = xd.W;
+    } else {
+      d.pad_t = pad_tl(xd.H);     // ZeroPadding2D(correct_pad) + 'valid'
+      d.pad_l = pad_tl(xd.W);
+      Ho = (xd.H + d.pad_t + 1 - 3) / 2 + 1;
+      Wo = (xd.W + d.pad_l + 1 - 3) / 2 + 1;
+    }
+    d.w = P(name + "/depthwise_kernel", {3, 3, xd.C, 1});
+    d.bn = BN(name + "_BN", xd.C, eps);
+    d.act = ACT_RELU6;
+    d.y = T(Ho, Wo, xd.C);
+    d.macs = (double)Ho * Wo * 9 * xd.C;
+    ops.push_back(d);
+    return d.y;
+  };
+  // Conv1: ZeroPadding2D(correct_pad) + Conv2D(32, 3, strides 2, valid, no bias) + BN + ReLU6
+  int x = conv("Conv1", input_tensor, 3, 3, 2, pad_tl(in_h), 32, false, BN("bn_Conv1", 32, eps), ACT_RELU6, -1, -1, 1,
+               true, none, ACT_NONE, nullptr, "/kernel", false, 1);
+  if (pad_tl(in_h) != pad_tl(in_w)) return set_error("mobilenet: height and width must have the same parity");
+  static const int cfg[7][4] = {{1, 16, 1, 1}, {6, 24, 2, 2}, {6, 32, 3, 2}, {6, 64, 4, 2}, {6, 96, 3, 1}, {6, 160, 3, 2},
+                                {6, 320, 1, 1}};
+  int block_id = 0, cin = 32;
+  for (int g = 0; g < 7; ++g) {
+    const int t = cfg[g][0], cout = cfg[g][1];
+    for (int i = 0; i < cfg[g][2]; ++i, ++block_id) {
+      const int stride = i == 0 ? cfg[g][3] : 1;
+      const std::string pre = block_id == 0 ? "expanded_conv" : "block_" + std::to_string(block_id);
+      int h = x;
+      if (block_id != 0)
+        h = conv(pre + "_expand", x, 1, 1, 1, 0, t * cin, false, BN(pre + "_expand_BN", t * cin, eps), ACT_RELU6, -1, -1,
+                 1, true, none, ACT_NONE, nullptr);
+      h = dw(pre + "_depthwise", h, stride);
+      const int res = (cin == cout && stride == 1) ? x : -1;
+      x = conv(pre + "_project", h, 1, 1, 1, 0, cout, false, BN(pre + "_project_BN", cout, eps), ACT_NONE, -1, res, 1, true,
+               none, ACT_NONE, nullptr);
+      cin = cout;
+    }
+  }
+  x = conv("Conv_1", x, 1, 1, 1, 0, 1280, false, BN("Conv_1_bn", 1280, eps), ACT_RELU6, -1, -1, 1, true, none, ACT_NONE,
+           nullptr);
+  return build_heads(x);
 }
 
 // ----------------------------------------------------------------------------- IResNet
@@ -652,14 +751,15 @@ int Net::build() {
     return build_iresnet(l);
   }
   if (arch == "nn4") return build_nn4();
+  if (arch == "vgg16") return build_vgg16();
+  if (arch == "mobilenet") return build_mobilenetv2();
   if (arch == "yolov3") return build_yolov3();
   if (arch == "iresnet100") {
     static const int l[4] = {3, 13, 30, 3};
     return build_iresnet(l);
   }
-  // the reference asserts net in ('mobilenet','resnet','vgg16') (triplet.py:77); only the
-  // ResNet path is on the hot path named by north_star
-  return set_error("Invalid bottleneck network '%s' (supported: resnet, iresnet50, iresnet100, nn4, yolov3)", arch.c_str());
+  return set_error("Invalid bottleneck network '%s' (supported: resnet, vgg16, mobilenet, iresnet50, iresnet100, nn4, "
+                   "yolov3)", arch.c_str());
 }
 
 double Net::flops_per_image() const {
@@ -739,7 +839,7 @@ int Net::finalize(int mb) {
       if (op.alpha < 0 && op.const_alpha != 0.f &&
           upload(this, std::vector<float>((size_t)op.Cout, op.const_alpha), &op.d_alpha))
         return -1;
-    } else if (op.kind == OP_DWFULL) {
+    } else if (op.kind == OP_DWFULL || op.kind == OP_DWCONV) {
       if (upload(this, params[op.w].data, &op.d_w)) return -1;   // [H][W][C][1] == [HW][C]
       fold(this, op.bn, -1, op.Cout, &scale, &shift);
       if (!scale.empty() && upload(this, scale, &op.d_scale)) return -1;
@@ -846,6 +946,7 @@ const char* Net::kernel_name(const Op& op, int n) const {
     case OP_INPUT: return "input_convert_kernel";
     case OP_MAXPOOL: return "maxpool_kernel";
     case OP_DWFULL: return "dwfull_kernel";
+    case OP_DWCONV: return "dwconv_kernel";
     case OP_L2NORM: return "l2norm_kernel";
     case OP_LRN: return "lrn_kernel";
     case OP_ZERO: return "memset";
@@ -1001,6 +1102,14 @@ int Net::run_op(const Op& op, Lane& L, const void* xin, int n, int layout, int d
     case OP_DWFULL: {
       const TensorDesc& xd = tensors[op.x];
       if (dwfull_run(ptr(op.x), op.d_w, op.d_scale, op.d_shift, ptr(op.y), n, xd.H * xd.W, xd.C, st)) return -1;
+      break;
+    }
+    case OP_DWCONV: {
+      const TensorDesc& xd = tensors[op.x];
+      const TensorDesc& yd = tensors[op.y];
+      if (dwconv_run(ptr(op.x), op.d_w, op.d_scale, op.d_shift, ptr(op.y), n, xd.H, xd.W, xd.C, op.KH, op.stride, op.pad_t,
+                     op.pad_l, yd.H, yd.W, op.act, st))
+        return -1;
       break;
     }
     case OP_LRN: {

@@ -37,7 +37,7 @@ struct TensorDesc {
   int64_t elems() const { return (int64_t)H * W * C; }
 };
 
-enum OpKind { OP_INPUT, OP_CONV, OP_MAXPOOL, OP_DWFULL, OP_L2NORM, OP_LRN, OP_ZERO, OP_UPSAMPLE, OP_COPY };
+enum OpKind { OP_INPUT, OP_CONV, OP_MAXPOOL, OP_DWFULL, OP_L2NORM, OP_LRN, OP_ZERO, OP_UPSAMPLE, OP_COPY, OP_DWCONV };
 
 struct Op {
   OpKind kind = OP_CONV;
@@ -142,6 +142,10 @@ struct Net {
            int* y2_out, const std::string& wsuffix = "/kernel", bool same_pad_even = false, int pad_br = -1);
   int build_yolov3();
   int build_resnet50v2();
+  void add_input();
+  int build_heads(int feat);         // v1 / v2 / v3 head of triplet.py:102-141 on a backbone's feature map
+  int build_vgg16();
+  int build_mobilenetv2();
   int build_iresnet(const int* layers);
   int build_nn4();
 };

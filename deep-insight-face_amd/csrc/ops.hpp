@@ -5,7 +5,7 @@
 
 namespace dif {
 
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_PRELU = 2 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_PRELU = 2, ACT_RELU6 = 3 };   // RELU6: min(max(x, 0), 6) (MobileNetV2)
 
 // Division of a non-negative int (< 2^31) by a launch-invariant divisor: one mul-hi and a
 // shift instead of the ~40-instruction expansion of a runtime integer division.
@@ -123,6 +123,10 @@ struct InputArgs {
 };
 int input_convert_run(const InputArgs& a, hipStream_t st);
 
+// depthwise KxK convolution + BN + activation: y[n,ho,wo,c] = act((sum_taps x * w[tap][c]) * scale[c] + shift[c]);
+// w is [K*K][C] (= Keras depthwise_kernel [K,K,C,1]); padded taps contribute zero
+int dwconv_run(const float* x, const float* w, const float* scale, const float* shift, float* y, int N, int H, int W,
+               int C, int K, int stride, int pad_t, int pad_l, int Ho, int Wo, int act, hipStream_t st);
 // depthwise conv whose kernel covers the whole map, + BN: y[n,c] = (sum_hw x*w) * scale + shift
 int dwfull_run(const float* x, const float* w, const float* scale, const float* shift, float* y, int N, int HW,
                int C, hipStream_t st);

@@ -219,17 +219,13 @@ class DifEmbedder:
 
 class bottleneck_network:
     """Same constructor and call as the reference (networks/triplet.py:73-85).  ``net`` is
-    'resnet' (ResNet50V2, the hot path) or -- extensions named by north_star --
-    'iresnet50' / 'iresnet100'.  'mobilenet' / 'vgg16' are accepted names in the reference
-    but are not part of the accelerated path."""
+    'resnet' (ResNet50V2, the hot path), 'mobilenet' (MobileNetV2) or 'vgg16' as in the reference
+    (triplet.py:87-93), or -- extensions named by north_star -- 'iresnet50' / 'iresnet100'."""
 
     def __init__(self, net: str = "resnet", emd_size: int = 128, input_shape: typing.Tuple = (96, 96, 3), **kwargs):
         # 'inception' is handled by the reference's picker (triplet.py:94-99) although its assert omits it
         assert net in ('mobilenet', 'resnet', 'vgg16', 'inception', 'iresnet50', 'iresnet100'), \
             "Invalid bottleneck network"
-        if net in ('mobilenet', 'vgg16'):
-            raise NotImplementedError("bottleneck '%s' is outside the MI355X hot path (resnet, iresnet50, iresnet100)"
-                                      % net)
         self.net = net
         self.emd_size = emd_size
         self.input_shape = input_shape

@@ -157,6 +157,101 @@ def resnet50v2_spec(in_ch=3):
     return spec
 
 
+# --------------------------------------------------------------------------- VGG16 / MobileNetV2
+# keras.applications.VGG16 / MobileNetV2(alpha=1.0), include_top=False: the other two backbones
+# bottleneck_network accepts (triplet.py:77,87-93).  Third-party, unpinned, absent from /root/reference
+# and not installed: restated from the public Keras layer tables (names and shapes as Keras has them).
+VGG16_CFG = ((64, 2), (128, 2), (256, 3), (512, 3), (512, 3))
+MOBILENETV2_CFG = ((1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2), (6, 96, 3, 1), (6, 160, 3, 2), (6, 320, 1, 1))
+MOBILENETV2_EPS = 1e-3
+
+
+def vgg16(x, p):
+    """[N,H,W,3] -> [N,H/32,W/32,512]: 13 x (Conv3x3 'same' + bias + ReLU), MaxPool2x2/2 after each block."""
+    y = x
+    for b, (c, n) in enumerate(VGG16_CFG, 1):
+        for i in range(1, n + 1):
+            name = 'block%d_conv%d' % (b, i)
+            y = relu(conv2d(y, p[name + '/kernel'], p[name + '/bias'], pad=(1, 1, 1, 1)))
+        y = maxpool(y, 2, 2)
+    return y
+
+
+def vgg16_spec(in_ch=3):
+    spec, cin = [], in_ch
+    for b, (c, n) in enumerate(VGG16_CFG, 1):
+        for i in range(1, n + 1):
+            spec += [('block%d_conv%d/kernel' % (b, i), (3, 3, cin, c)), ('block%d_conv%d/bias' % (b, i), (c,))]
+            cin = c
+    return spec
+
+
+def relu6(x):
+    return np.minimum(np.maximum(x, np.asarray(0, x.dtype)), np.asarray(6, x.dtype))
+
+
+def depthwise_conv2d(x, w, stride=1, pad=(0, 0, 0, 0)):
+    """x [N,H,W,C], w [kh,kw,C,1] (Keras depthwise_kernel), explicit zero padding."""
+    kh, kw = w.shape[:2]
+    xp = np.pad(x, ((0, 0), (pad[0], pad[1]), (pad[2], pad[3]), (0, 0)))
+    ho = (xp.shape[1] - kh) // stride + 1
+    wo = (xp.shape[2] - kw) // stride + 1
+    y = np.zeros((x.shape[0], ho, wo, x.shape[3]), dtype=x.dtype)
+    for i in range(kh):
+        for j in range(kw):
+            y += xp[:, i:i + (ho - 1) * stride + 1:stride, j:j + (wo - 1) * stride + 1:stride, :] * w[i, j, :, 0]
+    return y
+
+
+def _correct_pad(size):
+    """keras imagenet_utils.correct_pad for a 3x3 kernel: (before, after)."""
+    return (0, 1) if size % 2 == 0 else (1, 1)
+
+
+def mobilenetv2(x, p):
+    """[N,H,W,3] -> [N,H/32 (ceil),W/32,1280] (4x4x1280 at 112 px)."""
+    e = MOBILENETV2_EPS
+    ph, pw = _correct_pad(x.shape[1]), _correct_pad(x.shape[2])
+    y = relu6(batchnorm(conv2d(x, p['Conv1/kernel'], stride=2, pad=ph + pw), p, 'bn_Conv1', e))
+    block, cin = 0, 32
+    for t, c, n, s in MOBILENETV2_CFG:
+        for i in range(n):
+            stride = s if i == 0 else 1
+            pre = 'expanded_conv' if block == 0 else 'block_%d' % block
+            h = y
+            if block:
+                h = relu6(batchnorm(conv2d(h, p[pre + '_expand/kernel']), p, pre + '_expand_BN', e))
+            if stride == 1:
+                h = depthwise_conv2d(h, p[pre + '_depthwise/depthwise_kernel'], 1, (1, 1, 1, 1))
+            else:
+                h = depthwise_conv2d(h, p[pre + '_depthwise/depthwise_kernel'], 2,
+                                     _correct_pad(h.shape[1]) + _correct_pad(h.shape[2]))
+            h = relu6(batchnorm(h, p, pre + '_depthwise_BN', e))
+            h = batchnorm(conv2d(h, p[pre + '_project/kernel']), p, pre + '_project_BN', e)
+            y = y + h if (cin == c and stride == 1) else h
+            cin = c
+            block += 1
+    return relu6(batchnorm(conv2d(y, p['Conv_1/kernel']), p, 'Conv_1_bn', e))
+
+
+def mobilenetv2_spec(in_ch=3):
+    def bn(name, c):
+        return [(name + '/' + k, (c,)) for k in ('gamma', 'beta', 'moving_mean', 'moving_variance')]
+    spec = [('Conv1/kernel', (3, 3, in_ch, 32))] + bn('bn_Conv1', 32)
+    block, cin = 0, 32
+    for t, c, n, s in MOBILENETV2_CFG:
+        for i in range(n):
+            pre = 'expanded_conv' if block == 0 else 'block_%d' % block
+            mid = cin * t
+            if block:
+                spec += [(pre + '_expand/kernel', (1, 1, cin, mid))] + bn(pre + '_expand_BN', mid)
+            spec += [(pre + '_depthwise/depthwise_kernel', (3, 3, mid, 1))] + bn(pre + '_depthwise_BN', mid)
+            spec += [(pre + '_project/kernel', (1, 1, mid, c))] + bn(pre + '_project_BN', c)
+            cin = c
+            block += 1
+    return spec + [('Conv_1/kernel', (1, 1, cin, 1280))] + bn('Conv_1_bn', 1280)
+
+
 # --------------------------------------------------------------------------- heads
 def head_gdc(feat, p, emd):
     """build_models_v2, deep_insight_face/networks/triplet.py:119-141:
@@ -307,6 +402,15 @@ def model_spec(arch, emd=512, input_hw=112, head='v2'):
         elif head == 'v1':
             spec += head_v1_spec(2048, hw, emd)
         return spec
+    if arch in ('vgg16', 'mobilenet'):
+        spec = vgg16_spec() if arch == 'vgg16' else mobilenetv2_spec()
+        cfeat = 512 if arch == 'vgg16' else 1280
+        hw = input_hw // 32 if arch == 'vgg16' else -(-input_hw // 32)
+        if head == 'v2':
+            spec += head_gdc_spec(cfeat, hw, emd)
+        elif head == 'v1':
+            spec += head_v1_spec(cfeat, hw, emd)
+        return spec
     if arch in IRESNET_LAYERS:
         return iresnet_spec(arch, emd=emd, final_hw=input_hw // 16)
     if arch == 'nn4':
@@ -316,8 +420,8 @@ def model_spec(arch, emd=512, input_hw=112, head='v2'):
 
 def embed(x, p, arch, emd=512, head='v2'):
     """x: [N,H,W,3] already scaled (predictions.py:154 multiplies by 1/255)."""
-    if arch == 'resnet':
-        f = resnet50v2(x, p)
+    if arch in ('resnet', 'vgg16', 'mobilenet'):
+        f = {'resnet': resnet50v2, 'vgg16': vgg16, 'mobilenet': mobilenetv2}[arch](x, p)
         if head == 'v2':
             return head_gdc(f, p, emd)
         if head == 'v1':

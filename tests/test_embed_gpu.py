@@ -35,7 +35,9 @@ def build(arch, head, emd, max_batch=8):
 
 @pytest.mark.parametrize('arch,head,emd,n', [('resnet', 'v2', 512, 8), ('resnet', 'v1', 128, 5),
                                              ('resnet', 'v3', 512, 3), ('iresnet50', 'v2', 512, 3),
-                                             ('iresnet100', 'v2', 512, 2)])
+                                             ('iresnet100', 'v2', 512, 2), ('vgg16', 'v2', 512, 3),
+                                             ('mobilenet', 'v2', 512, 5), ('mobilenet', 'v3', 512, 2),
+                                             ('mobilenet', 'v1', 128, 2)])
 def test_embed_vs_oracle(cuda, arch, head, emd, n):
     model, p = build(arch, head, emd)
     x = scaled(crops_u8(n))

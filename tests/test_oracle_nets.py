@@ -29,6 +29,10 @@ def test_param_counts_and_shapes():
     assert n(nets.resnet50v2_spec()) == 23_564_800            # keras ResNet50V2(include_top=False)
     assert n(nets.model_spec('iresnet100', 512)) == 65_225_792
     assert n(nets.model_spec('iresnet50', 512)) == 43_628_992
+    assert n(nets.vgg16_spec()) == 14_714_688                 # keras VGG16(include_top=False)
+    assert n(nets.mobilenetv2_spec()) == 2_257_984            # keras MobileNetV2(alpha=1.0, include_top=False)
+    assert nets.mobilenetv2(crops(1), synth('mobilenet', 512, 'v3')).shape == (1, 4, 4, 1280)
+    assert nets.vgg16(crops(1), synth('vgg16', 512, 'v3')).shape == (1, 3, 3, 512)
     p = synth('resnet', 512, 'v3')
     f = nets.embed(crops(1), p, 'resnet', head='v3')
     assert f.shape == (1, 4, 4, 2048)
@@ -39,7 +43,8 @@ def test_param_counts_and_shapes():
 def test_library_param_table_matches_oracle():
     from deep_insight_face.networks.triplet import DifEmbedder
     for arch, head, emd in (('resnet', 'v2', 512), ('resnet', 'v1', 128), ('resnet', 'v3', 512),
-                            ('iresnet50', 'v2', 512), ('iresnet100', 'v2', 512)):
+                            ('iresnet50', 'v2', 512), ('iresnet100', 'v2', 512), ('vgg16', 'v2', 512),
+                            ('mobilenet', 'v1', 128), ('mobilenet', 'v2', 512), ('mobilenet', 'v3', 512)):
         m = DifEmbedder(arch, head, emd, (112, 112, 3))
         assert dict(m.param_spec()) == dict(nets.model_spec(arch, emd, 112, head)), (arch, head)
         m.close()
@@ -52,7 +57,9 @@ def test_library_param_table_matches_oracle():
 
 
 @pytest.mark.parametrize('arch,head,emd,n', [('resnet', 'v2', 512, 2), ('resnet', 'v1', 128, 2),
-                                             ('resnet', 'v3', 512, 1), ('iresnet50', 'v2', 512, 1)])
+                                             ('resnet', 'v3', 512, 1), ('iresnet50', 'v2', 512, 1),
+                                             ('vgg16', 'v2', 512, 1), ('mobilenet', 'v2', 512, 2),
+                                             ('mobilenet', 'v3', 512, 1)])
 def test_oracle_vs_torch(arch, head, emd, n):
     p = synth(arch, emd, head)
     x = crops(n)

@@ -82,11 +82,51 @@ def iresnet(x, p, layers):
     return y / y.pow(2).sum(1, keepdim=True).clamp_min(1e-12).sqrt()
 
 
+def vgg16(x, p):
+    y = x
+    for b, n in enumerate((2, 2, 3, 3, 3), 1):
+        for i in range(1, n + 1):
+            y = F.relu(_conv(y, p, 'block%d_conv%d' % (b, i), 1, 1))
+        y = F.max_pool2d(y, 2, 2)
+    return y
+
+
+def mobilenetv2(x, p):
+    eps = 1e-3
+
+    def cpad(t):                       # keras correct_pad, as F.pad's (left, right, top, bottom)
+        h, w = t.shape[2], t.shape[3]
+        return ((0, 1) if w % 2 == 0 else (1, 1)) + ((0, 1) if h % 2 == 0 else (1, 1))
+
+    def dw(t, name, stride):
+        k = _t(p, name + '/depthwise_kernel').permute(2, 3, 0, 1).contiguous()     # [3,3,C,1] -> [C,1,3,3]
+        if stride == 2:
+            return F.conv2d(F.pad(t, cpad(t)), k, None, stride=2, groups=t.shape[1])
+        return F.conv2d(t, k, None, stride=1, padding=1, groups=t.shape[1])
+
+    y = F.relu6(_bn(_conv(x, p, 'Conv1', 2, cpad(x), bias=False), p, 'bn_Conv1', eps))
+    block, cin = 0, 32
+    for t, c, n, s in ((1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2), (6, 96, 3, 1), (6, 160, 3, 2),
+                       (6, 320, 1, 1)):
+        for i in range(n):
+            stride = s if i == 0 else 1
+            pre = 'expanded_conv' if block == 0 else 'block_%d' % block
+            h = y
+            if block:
+                h = F.relu6(_bn(_conv(h, p, pre + '_expand', bias=False), p, pre + '_expand_BN', eps))
+            h = F.relu6(_bn(dw(h, pre + '_depthwise', stride), p, pre + '_depthwise_BN', eps))
+            h = _bn(_conv(h, p, pre + '_project', bias=False), p, pre + '_project_BN', eps)
+            y = y + h if (cin == c and stride == 1) else h
+            cin = c
+            block += 1
+    return F.relu6(_bn(_conv(y, p, 'Conv_1', bias=False), p, 'Conv_1_bn', eps))
+
+
 def embed(x_nhwc, p, arch, head='v2'):
     x = torch.from_numpy(x_nhwc).permute(0, 3, 1, 2).contiguous()
     with torch.no_grad():
-        if arch == 'resnet':
-            f = resnet50v2(x, p)
+        if arch in ('resnet', 'vgg16', 'mobilenet'):
+            f = {'resnet': resnet50v2, 'vgg16': vgg16, 'mobilenet': mobilenetv2}[arch](x, p)
             if head == 'v2':
                 return head_gdc(f, p).numpy()
             if head == 'v1':

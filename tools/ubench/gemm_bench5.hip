@@ -82,6 +82,80 @@ __global__ __launch_bounds__(256, 4) void k(const float* A, const float* B, floa
   }
 }
 
+// LDS-DMA operand staging (no VGPR round trip, no ds_write) with a ring of NST stages of one 32-wide
+// K-step each; NST = 2 fits four blocks per CU, NST = 3 (operands fetched two steps ahead) three.
+template <int NST, int MINB>
+__global__ __launch_bounds__(256, MINB) void kdma(const float* A, const float* B, float* C, int M, int N, int K) {
+  using T = Tile<1, 1>;
+  constexpr int NA = T::NA, NB = T::NB, RP = T::RP;
+  constexpr int BUF = (64 + 64) * BK, OFFB = 64 * BK;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wr = T::wave_row(), wc = T::wave_col();
+  const int tiles_n = N / 64;
+  const int KS = K / 32;
+  const int r = lane & 31, h = lane >> 5;
+  const int f = dma_swizzle(r);
+  for (int tile = blockIdx.x; tile < (M / 64) * tiles_n; tile += gridDim.x) {
+    const int m0 = (tile / tiles_n) * 64, n0 = (tile % tiles_n) * 64;
+    DmaRowLoader<NA, RP> al(A + (int64_t)m0 * K, M - m0, K);
+    DmaRowLoader<NB, RP> bl(B + (int64_t)n0 * K, N - n0, K);
+    f32x16 acc;
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    // prime NST-1 stages
+    for (int s = 0; s < NST - 1; ++s)
+      if (s < KS) { al.issue(s, lds + s * BUF); bl.issue(s, lds + s * BUF + OFFB); }
+    if (NST == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (int ks = 0; ks < KS; ++ks) {
+      int nxt = cur + (NST - 1); if (nxt >= NST) nxt -= NST;
+      if (ks + NST - 1 < KS) { al.issue(ks + NST - 1, lds + nxt * BUF); bl.issue(ks + NST - 1, lds + nxt * BUF + OFFB); }
+      const float* pa = lds + cur * BUF + (wr * 32 + r) * BK;
+      const float* pb = lds + cur * BUF + OFFB + (wc * 32 + r) * BK;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int c0 = ((2 * h + 4 * s) ^ f) * 4, c1 = ((2 * h + 4 * s + 1) ^ f) * 4;
+        const f32x4 fa0 = *reinterpret_cast<const f32x4*>(pa + c0), fa1 = *reinterpret_cast<const f32x4*>(pa + c1);
+        const f32x4 fb0 = *reinterpret_cast<const f32x4*>(pb + c0), fb1 = *reinterpret_cast<const f32x4*>(pb + c1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[t], fb0[t], acc, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[t], fb1[t], acc, 0, 0, 0);
+      }
+      // the stage the NEXT step reads must have landed: with three stages the youngest four pieces
+      // (the stage after it) may still be in flight
+      if (NST == 3 && ks + 2 < KS) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      cur = cur + 1 == NST ? 0 : cur + 1;
+    }
+    float sacc = 0.f;
+    for (int q = 0; q < 16; ++q) sacc += acc[q];
+    C[(int64_t)tile * 256 + tid] = sacc;
+    __syncthreads();
+  }
+}
+
+template <int NST, int MINB>
+static void run_dma(const char* name, const float* A, const float* B, float* C, int M, int N, int K) {
+  auto kern = kdma<NST, MINB>;
+  const int lds = NST * (64 + 64) * BK * 4;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const int grid = MINB * 256;
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, A, B, C, M, N, K);
+  CK(hipEventRecord(e0));
+  const int reps = 10;
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, A, B, C, M, N, K);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= reps;
+  printf("%-46s %8.3f ms  %6.1f TFLOP/s (%.1f %% of 157.3)\n", name, ms, 2.0 * M * N * K / ms / 1e9, 2.0 * M * N * K / ms / 1e9 / 1.573);
+}
+
 template <int V>
 static void run(const char* name, const float* A, const float* B, float* C, int M, int N, int K) {
   auto kern = k<V>;
@@ -111,15 +185,22 @@ int main(int argc, char** argv) {
   h.resize((size_t)N * K);
   CK(hipMemcpy(B, h.data(), (size_t)N * K * 4, hipMemcpyHostToDevice));
   printf("M=%d N=%d K=%d, 64x64 tile, 1024 persistent blocks (4 per CU)\n", M, N, K);
-  run<0>("full loop", A, B, C, M, N, K);
-  run<1>("no barrier", A, B, C, M, N, K);
-  run<2>("no global loads", A, B, C, M, N, K);
-  run<4>("no LDS fragment reads", A, B, C, M, N, K);
-  run<8>("no LDS staging writes", A, B, C, M, N, K);
-  run<2 | 8>("no global loads, no staging writes", A, B, C, M, N, K);
-  run<1 | 2 | 8>("no barrier, no loads, no staging", A, B, C, M, N, K);
-  run<1 | 2 | 4 | 8>("MFMA only", A, B, C, M, N, K);
-  run<16>("full loop, fragment reads up front", A, B, C, M, N, K);
-  run<16 | 2 | 8>("frag up front, no loads/staging", A, B, C, M, N, K);
+  for (int pass = 0; pass < 3; ++pass) {
+    printf("-- pass %d\n", pass);
+    run<0>("full loop (register staging, 4 blocks/CU)", A, B, C, M, N, K);
+    run<16>("  + fragment reads up front", A, B, C, M, N, K);
+    run_dma<2, 4>("LDS-DMA, 2 stages, 4 blocks/CU", A, B, C, M, N, K);
+    run_dma<2, 3>("LDS-DMA, 2 stages, 3 blocks/CU", A, B, C, M, N, K);
+    run_dma<3, 3>("LDS-DMA, 3 stages, 3 blocks/CU", A, B, C, M, N, K);
+    run_dma<2, 2>("LDS-DMA, 2 stages, 2 blocks/CU", A, B, C, M, N, K);
+    run_dma<3, 2>("LDS-DMA, 3 stages, 2 blocks/CU", A, B, C, M, N, K);
+    if (pass == 0) {
+      run<1>("no barrier", A, B, C, M, N, K);
+      run<2>("no global loads", A, B, C, M, N, K);
+      run<4>("no LDS fragment reads", A, B, C, M, N, K);
+      run<2 | 8>("no global loads, no staging writes", A, B, C, M, N, K);
+      run<1 | 2 | 4 | 8>("MFMA only", A, B, C, M, N, K);
+    }
+  }
   return 0;
 }
