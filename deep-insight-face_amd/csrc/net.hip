@@ -321,7 +321,39 @@ int Net::build_heads(int feat) {
     output_tensor = e;
     return 0;
   }
-  return set_error("unknown head '%s' (v1, v2, v3)", head.c_str());
+  if (head == "sv2") {
+    // networks/siamese.py:107-128 (the siamese builder's v2): Conv1x1(128, bias, relu) -> MaxPooling2D('same') ->
+    // Conv1x1(128, bias, relu) -> MaxPooling2D('same') -> BatchNormalization("bn") -> Flatten -> Dropout ->
+    // Dense(emd, relu, "norm_embedding").  The BN sits between a pool and the dense layer: it is applied to
+    // the dense layer's input while that is gathered (the pre-activation path, without an activation).
+    auto pool_same2 = [&](int src, const char* nm) {
+      const TensorDesc td = tensors[src];
+      Op p;
+      p.kind = OP_MAXPOOL;
+      p.name = nm;
+      p.x = src;
+      p.KH = p.KW = 2;
+      p.stride = 2;
+      p.Cin = p.Cout = td.C;
+      p.y = T((td.H + 1) / 2, (td.W + 1) / 2, td.C);     // 'same': ceil; the extra tap is outside the map, ignored by max
+      ops.push_back(p);
+      return p.y;
+    };
+    int a = conv("sv2_conv1", feat, 1, 1, 1, 0, 128, true, none, ACT_RELU, -1, -1, 1, true, none, ACT_NONE, nullptr);
+    a = pool_same2(a, "sv2_pool1");
+    int b = conv("sv2_conv2", a, 1, 1, 1, 0, 128, true, none, ACT_RELU, -1, -1, 1, true, none, ACT_NONE, nullptr);
+    b = pool_same2(b, "sv2_pool2");
+    const TensorDesc bd = tensors[b];
+    const BNRef bn = BN("bn", 128, EPS_KERAS);
+    int e = conv("norm_embedding", b, bd.H, bd.W, 1, 0, emd, true, none, ACT_RELU, -1, -1, 1, true, none, ACT_NONE,
+                 nullptr);
+    ops.back().pre_bn = bn;
+    ops.back().pre_act = ACT_NONE;
+    params[ops.back().w].shape = {(int64_t)bd.H * bd.W * bd.C, emd};
+    output_tensor = e;
+    return 0;
+  }
+  return set_error("unknown head '%s' (v1, v2, v3, sv2)", head.c_str());
 }
 
 // ----------------------------------------------------------------------------- VGG16 / MobileNetV2

@@ -271,6 +271,28 @@ def head_gdc(feat, p, emd):
     return l2_normalize(y)
 
 
+def head_sv2(feat, p, emd):
+    """The siamese builder's build_models_v2, deep_insight_face/networks/siamese.py:107-128:
+    Conv1x1(128, bias, relu) -> MaxPooling2D(padding='same') -> Conv1x1(128, bias, relu) ->
+    MaxPooling2D(padding='same') -> BatchNormalization -> Flatten -> [Dropout] -> Dense(emd, relu)."""
+    def pool_same(y):
+        ph, pw = y.shape[1] % 2, y.shape[2] % 2           # 'same' for k = 2, s = 2: pad after on odd sizes
+        return maxpool(y, 2, 2, pad=(0, ph, 0, pw), pad_value=-np.inf)
+    y = pool_same(relu(conv2d(feat, p['sv2_conv1/kernel'], p['sv2_conv1/bias'])))
+    y = pool_same(relu(conv2d(y, p['sv2_conv2/kernel'], p['sv2_conv2/bias'])))
+    y = batchnorm(y, p, 'bn', BN_EPS_KERAS)
+    y = y.reshape(y.shape[0], -1)
+    return relu(y @ p['norm_embedding/kernel'] + p['norm_embedding/bias'])
+
+
+def head_sv2_spec(cin, hw, emd):
+    h2 = -(-(-(-hw // 2)) // 2)
+    return ([('sv2_conv1/kernel', (1, 1, cin, 128)), ('sv2_conv1/bias', (128,)),
+             ('sv2_conv2/kernel', (1, 1, 128, 128)), ('sv2_conv2/bias', (128,))] +
+            [('bn/' + k, (128,)) for k in ('gamma', 'beta', 'moving_mean', 'moving_variance')] +
+            [('norm_embedding/kernel', (h2 * h2 * 128, emd)), ('norm_embedding/bias', (emd,))])
+
+
 def head_gdc_spec(cin, hw, emd):
     def bn(name, c):
         return [(name + '/' + k, (c,)) for k in ('gamma', 'beta', 'moving_mean', 'moving_variance')]
@@ -401,6 +423,8 @@ def model_spec(arch, emd=512, input_hw=112, head='v2'):
             spec += head_gdc_spec(2048, hw, emd)
         elif head == 'v1':
             spec += head_v1_spec(2048, hw, emd)
+        elif head == 'sv2':
+            spec += head_sv2_spec(2048, hw, emd)
         return spec
     if arch in ('vgg16', 'mobilenet'):
         spec = vgg16_spec() if arch == 'vgg16' else mobilenetv2_spec()
@@ -410,6 +434,8 @@ def model_spec(arch, emd=512, input_hw=112, head='v2'):
             spec += head_gdc_spec(cfeat, hw, emd)
         elif head == 'v1':
             spec += head_v1_spec(cfeat, hw, emd)
+        elif head == 'sv2':
+            spec += head_sv2_spec(cfeat, hw, emd)
         return spec
     if arch in IRESNET_LAYERS:
         return iresnet_spec(arch, emd=emd, final_hw=input_hw // 16)
@@ -426,6 +452,8 @@ def embed(x, p, arch, emd=512, head='v2'):
             return head_gdc(f, p, emd)
         if head == 'v1':
             return head_v1(f, p, emd)
+        if head == 'sv2':
+            return head_sv2(f, p, emd)
         if head == 'v3':
             return f
         raise ValueError(head)

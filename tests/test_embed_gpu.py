@@ -28,7 +28,11 @@ def cosine_gap(a, b):
 
 def build(arch, head, emd, max_batch=8):
     from deep_insight_face.networks.triplet import bottleneck_network
-    model = bottleneck_network(arch, emd, (112, 112, 3), max_batch=max_batch)(head)
+    if head == 'sv2':                      # the siamese builder's v2 head (networks/siamese.py:107-128)
+        from deep_insight_face.networks import siamese
+        model = siamese.bottleneck_network(arch, emd, (112, 112, 3), max_batch=max_batch)('v2')
+    else:
+        model = bottleneck_network(arch, emd, (112, 112, 3), max_batch=max_batch)(head)
     model.init_synthetic(2024)
     return model, model.get_weights()
 
@@ -37,7 +41,8 @@ def build(arch, head, emd, max_batch=8):
                                              ('resnet', 'v3', 512, 3), ('iresnet50', 'v2', 512, 3),
                                              ('iresnet100', 'v2', 512, 2), ('vgg16', 'v2', 512, 3),
                                              ('mobilenet', 'v2', 512, 5), ('mobilenet', 'v3', 512, 2),
-                                             ('mobilenet', 'v1', 128, 2)])
+                                             ('mobilenet', 'v1', 128, 2), ('resnet', 'sv2', 128, 3),
+                                             ('vgg16', 'sv2', 128, 2)])
 def test_embed_vs_oracle(cuda, arch, head, emd, n):
     model, p = build(arch, head, emd)
     x = scaled(crops_u8(n))

@@ -44,7 +44,8 @@ def test_library_param_table_matches_oracle():
     from deep_insight_face.networks.triplet import DifEmbedder
     for arch, head, emd in (('resnet', 'v2', 512), ('resnet', 'v1', 128), ('resnet', 'v3', 512),
                             ('iresnet50', 'v2', 512), ('iresnet100', 'v2', 512), ('vgg16', 'v2', 512),
-                            ('mobilenet', 'v1', 128), ('mobilenet', 'v2', 512), ('mobilenet', 'v3', 512)):
+                            ('mobilenet', 'v1', 128), ('mobilenet', 'v2', 512), ('mobilenet', 'v3', 512), ('resnet', 'sv2', 128),
+                            ('vgg16', 'sv2', 64)):
         m = DifEmbedder(arch, head, emd, (112, 112, 3))
         assert dict(m.param_spec()) == dict(nets.model_spec(arch, emd, 112, head)), (arch, head)
         m.close()
@@ -59,7 +60,8 @@ def test_library_param_table_matches_oracle():
 @pytest.mark.parametrize('arch,head,emd,n', [('resnet', 'v2', 512, 2), ('resnet', 'v1', 128, 2),
                                              ('resnet', 'v3', 512, 1), ('iresnet50', 'v2', 512, 1),
                                              ('vgg16', 'v2', 512, 1), ('mobilenet', 'v2', 512, 2),
-                                             ('mobilenet', 'v3', 512, 1)])
+                                             ('mobilenet', 'v3', 512, 1), ('resnet', 'sv2', 128, 2),
+                                             ('vgg16', 'sv2', 128, 1)])
 def test_oracle_vs_torch(arch, head, emd, n):
     p = synth(arch, emd, head)
     x = crops(n)

@@ -132,3 +132,31 @@ def test_two_lane_forward_matches_single_lane(cuda, monkeypatch):
     assert cosine_gap(a[rows], want).max() < 1e-5
     two.close()
     one.close()
+
+
+def test_siamese_module(cuda):
+    """networks/siamese.py mirror: euclidean_distance = sqrt(max(sum sq diff, eps)) keepdims, the
+    two-tower model = distance between the shared tower's embeddings, the siamese v2 head."""
+    from deep_insight_face.networks import siamese
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal((7, 128)).astype(np.float32)
+    b = rng.standard_normal((7, 128)).astype(np.float32)
+    b[2] = a[2]
+    want = np.sqrt(np.maximum(((a - b) ** 2).sum(1, keepdims=True), 1e-7))
+    got = siamese.euclidean_distance((a, b))
+    assert got.shape == (7, 1)
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+    assert siamese.eucl_dist_output_shape(((7, 128), (7, 128))) == (7, 1)
+    model, base = siamese.buildin_models(128, (112, 112, 3), max_batch=4)
+    base.init_synthetic(9)
+    x1, x2 = crops_u8(3, seed=1).astype(np.float32) / 255, crops_u8(3, seed=2).astype(np.float32) / 255
+    d = model.predict([x1, x2])
+    e1, e2 = base.predict_on_batch(x1), base.predict_on_batch(x2)
+    np.testing.assert_allclose(d, np.sqrt(np.maximum(((e1 - e2) ** 2).sum(1, keepdims=True), 1e-7)), rtol=1e-4, atol=1e-5)
+    assert float(model.predict([x1, x1]).max()) < 1e-3
+    v2 = siamese.bottleneck_network('resnet', 64, (112, 112, 3), max_batch=2)('v2')
+    assert v2.output_shape == (64,) and dict(v2.param_spec())['norm_embedding/kernel'] == (128, 64)
+    with pytest.raises(AssertionError, match='Invalid bottleneck network'):
+        siamese.bottleneck_network('inception')
+    base.close()
+    v2.close()

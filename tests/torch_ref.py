@@ -63,6 +63,14 @@ def head_v1(f, p):
     return y @ _t(p, 'embeddings/kernel') + _t(p, 'embeddings/bias')
 
 
+def head_sv2(f, p):
+    y = F.max_pool2d(F.relu(_conv(f, p, 'sv2_conv1')), 2, 2, ceil_mode=True)
+    y = F.max_pool2d(F.relu(_conv(y, p, 'sv2_conv2')), 2, 2, ceil_mode=True)
+    y = _bn(y, p, 'bn', 1e-3)
+    y = y.permute(0, 2, 3, 1).reshape(y.shape[0], -1)                  # Keras flattens NHWC
+    return F.relu(y @ _t(p, 'norm_embedding/kernel') + _t(p, 'norm_embedding/bias'))
+
+
 def iresnet(x, p, layers):
     eps = 1e-5
     y = F.prelu(_bn(_conv(x, p, 'conv1', 1, 1, bias=False), p, 'bn1', eps), _t(p, 'prelu/alpha'))
@@ -131,6 +139,8 @@ def embed(x_nhwc, p, arch, head='v2'):
                 return head_gdc(f, p).numpy()
             if head == 'v1':
                 return head_v1(f, p).numpy()
+            if head == 'sv2':
+                return head_sv2(f, p).numpy()
             return f.permute(0, 2, 3, 1).contiguous().numpy()
         layers = {'iresnet50': (3, 4, 14, 3), 'iresnet100': (3, 13, 30, 3)}[arch]
         return iresnet(x, p, layers).numpy()
