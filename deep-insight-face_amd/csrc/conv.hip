@@ -447,7 +447,24 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const 
   const int tiles_n = (a.Cout + T::BN - 1) / T::BN;
   const int tiles_m = (a.M + T::BM - 1) / T::BM;
   const int I = tiles_m * tiles_n * KS;                       // < 2^31 (checked by conv_run)
-  const int beg = (int)((int64_t)I * p / P), end = (int)((int64_t)I * (p + 1) / P);
+  // Start of (remapped) block q's share of the iteration space.  With the chip full (P = 4 blocks on every
+  // CU) the four co-resident blocks do NOT advance at the same rate: the wave arbiter favours older waves,
+  // so the block dispatched first to a CU finishes an equal share ~20 % earlier than the one dispatched
+  // last (477 / 512 / 554 / 583 us measured on a 595 us launch) and the CU idles while the late ones
+  // finish.  Shares are therefore weighted by the resident slot, w = 1 + skew * (1.5 - slot): in remapped
+  // order an XCD's 128 blocks are four runs of 32 (slot 0..3), so the prefix sum is piecewise linear.
+  // skew_q16 = 0 gives the equal split; the split stays a pure function of the problem (deterministic).
+  const int skew = a.sk_skew_q16;
+  auto sk_begin = [&](int q) -> int {
+    if (skew == 0 || q >= P) return (int)((int64_t)I * q / P);
+    const int j = q & 127, g = j >> 5, r = j & 31;
+    // 65536 * (32 * sum_{s<g} w_s + r * w_g), with w_s = 1 + skew * (1.5 - s)
+    const int64_t wsum = (int64_t)g * 32 * 65536 + (int64_t)skew * 16 * (3 * g - g * (g - 1));
+    const int64_t wg = 65536 + (int64_t)skew * (3 - 2 * g) / 2;
+    const int64_t W = (int64_t)(q - j) * 65536 + wsum + r * wg;      // q - j = whole XCD runs before this one
+    return (int)(((int64_t)I * W) / ((int64_t)P * 65536));      // I < 2^31, W <= 2^26
+  };
+  const int beg = sk_begin(p), end = sk_begin(p + 1);
 
   // development aid: time per phase, summed over the block's tiles (100 MHz ticks)
   unsigned long long tr_main = 0, tr_fix = 0, tr_epi = 0, tr_steps = 0, tr_tiles = 0;
@@ -511,7 +528,7 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const 
       int q = p;
       while (kdone < KS) {
         ++q;
-        const int qb = (int)((int64_t)I * q / P), qe = (int)((int64_t)I * (q + 1) / P);   // starts inside this tile
+        const int qb = sk_begin(q), qe = sk_begin(q + 1);   // starts inside this tile
         const int q_kb = qb - tile * KS;
         const int q_len = qe - qb;
         const int q_ke = (KS - q_kb <= q_len) ? KS : q_kb + q_len;
@@ -924,6 +941,11 @@ static int launch_conv_pre(const ConvArgs& a, hipStream_t st) {
   }
   if (P < 1) P = 1;
   ConvArgs b = a;
+  {
+    // slot-weighted stream-K shares: only when the grid is exactly four blocks on each of 256 CUs
+    static const int skew_q16 = (int)((getenv("DIF_SK_SKEW") ? atof(getenv("DIF_SK_SKEW")) : 0.0) * 65536.0);
+    b.sk_skew_q16 = (P == 1024 && P != tiles && num_cus() == 256) ? skew_q16 : 0;
+  }
   b.fd_howo = make_fastdiv(a.Ho * a.Wo);
   b.fd_wo = make_fastdiv(a.Wo);
   b.fd_cin = make_fastdiv(a.Cin);

@@ -75,6 +75,7 @@ struct ConvArgs {
   unsigned* sk_flag;
   unsigned sk_epoch;
   int sk_max_blocks;
+  int sk_skew_q16;      // stream-K share skew by resident slot, Q16 (conv.hip: sk_begin); filled by conv_run
   int sk_spin_limit;    // polls before the owner computes a missing K range itself; < 0: always (test hook)
   int dbg;              // development aid: bit 0 drops the pipelined kernel's stores, bit 1 its shortcut loads
   // development aid (tools/ubench/conv_trace.hip), null in the library: 4 x u64 per hardware block =

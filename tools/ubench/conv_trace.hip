@@ -91,6 +91,31 @@ int main(int argc, char** argv) {
     ++nb;
   }
   if (!nb) { printf("(no trace records)\n"); return 0; }
+  {
+    std::vector<double> st, en;
+    for (int64_t b = 0; b < max_tiles; ++b) if (t[(size_t)b * 8 + 7]) { st.push_back((t[b * 8 + 5] - tmin) * 0.01); en.push_back((t[b * 8 + 6] - tmin) * 0.01); }
+    std::sort(st.begin(), st.end()); std::sort(en.begin(), en.end());
+    printf("block start (us) p50 %.1f p99 %.1f max %.1f | block end p1 %.1f p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f\n", st[nb / 2],
+           st[nb * 99 / 100], st[nb - 1], en[nb / 100], en[nb / 10], en[nb / 2], en[nb * 9 / 10], en[nb * 99 / 100], en[nb - 1]);
+  }
+  if (getenv("SHOW_MAP")) {
+    double ex[8] = {0}, es[4] = {0}; int nx[8] = {0}, ns[4] = {0};
+    for (int b = 0; b < 1024 && b < max_tiles; ++b) if (t[(size_t)b * 8 + 7]) {
+      const double e = (t[b * 8 + 6] - tmin) * 0.01;
+      ex[b & 7] += e; nx[b & 7]++; es[(b >> 8) & 3] += e; ns[(b >> 8) & 3]++;
+    }
+    printf("mean block end by XCD (b %% 8):");
+    for (int x = 0; x < 8; ++x) printf(" %.1f", ex[x] / (nx[x] ? nx[x] : 1));
+    printf(" | by resident slot (b >> 8):");
+    for (int x = 0; x < 4; ++x) printf(" %.1f", es[x] / (ns[x] ? ns[x] : 1));
+    printf("\n");
+    // per CU within XCD 0: blocks b with b%8==0: CU index j%32 where j=b>>3
+    double ec[32] = {0}; int nc[32] = {0};
+    for (int b = 0; b < 1024 && b < max_tiles; b += 8) if (t[(size_t)b * 8 + 7]) { const int cu = (b >> 3) & 31; ec[cu] += (t[b * 8 + 6] - tmin) * 0.01; nc[cu]++; }
+    printf("XCD 0, mean block end by CU (dispatch order):");
+    for (int c = 0; c < 32; ++c) printf(" %.0f", ec[c] / (nc[c] ? nc[c] : 1));
+    printf("\n");
+  }
   if (kind == 2)
     printf("pipelined kernel: %d blocks, %.2f tiles/block, span %.1f us, mean block life %.1f us; per tile: set-up %.2f us, first loads -> LDS %.2f us, "
            "K-steps %.2f us, hand-over %.2f us\n", nb, v[4] / nb, (tmax - tmin) * 0.01, life / nb, v[0] * 0.01 / v[4], v[1] * 0.01 / v[4],
