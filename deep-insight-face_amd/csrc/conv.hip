@@ -469,6 +469,7 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const 
   // development aid: time per phase, summed over the block's tiles (100 MHz ticks)
   unsigned long long tr_main = 0, tr_fix = 0, tr_epi = 0, tr_steps = 0, tr_tiles = 0;
   const unsigned long long tr_t0 = a.trace ? __builtin_amdgcn_s_memrealtime() : 0;
+  const unsigned long long tr_c0 = a.trace ? __builtin_amdgcn_s_memtime() : 0;
   int it = beg;
   while (it < end) {
     const unsigned long long tA = a.trace ? __builtin_amdgcn_s_memrealtime() : 0;
@@ -585,7 +586,8 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const 
     unsigned long long* t = a.trace + (size_t)blockIdx.x * 8;
     t[0] = tr_main; t[1] = tr_fix; t[2] = tr_epi; t[3] = tr_steps; t[4] = tr_tiles; t[5] = tr_t0;
     t[6] = __builtin_amdgcn_s_memrealtime();
-    t[7] = 1;   // 1 = conv_igemm_kernel record, 2 = conv_pipe_kernel record
+    // low byte: 1 = conv_igemm_kernel record, 2 = conv_pipe_kernel record; above it: shader-clock cycles of the block
+    t[7] = 1 | ((__builtin_amdgcn_s_memtime() - tr_c0) << 8);
   }
 }
 
@@ -727,6 +729,7 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_pipe_kernel(const C
         ald.load(ks + 1, ra);
         bld.load(ks + 1, rb);
       }
+      __builtin_amdgcn_sched_barrier(0);   // the prefetch stays above the MFMAs (see gemm_mainloop2)
       if constexpr (J * CPS < 8) {
         epi_pre(std::integral_constant<int, J * CPS>());
         if constexpr (CPS > 1) epi_pre(std::integral_constant<int, J * CPS + 1>());

@@ -99,6 +99,7 @@ __device__ __forceinline__ void gemm_mainloop(ALoader& al, BLoader& bl, int kbeg
       al.load(ks + 1, ra);
       bl.load(ks + 1, rb);
     }
+    __builtin_amdgcn_sched_barrier(0);   // the prefetch stays above the MFMAs (see gemm_mainloop2)
     const float* pa = lds + cur * BUF + (wr * WM * 32) * LDS_STRIDE + fr_off;
     const float* pb = lds + cur * BUF + OFFB + (wc * WN * 32) * LDS_STRIDE + fr_off;
 #pragma unroll
@@ -202,6 +203,10 @@ __device__ __forceinline__ void gemm_mainloop2(ALoader& al, BLoader& bl, int kbe
     const int cur = (ks - kbeg) & 1;
     al.load(ks + 1, ra);
     bl.load(ks + 1, rb);
+    // keep the prefetch where it is written: left alone, the scheduler sinks these loads below the
+    // MFMAs, right in front of the LDS writes that consume them, and the loop stops overlapping
+    // global-load latency with matrix work at all
+    __builtin_amdgcn_sched_barrier(0);
     mfma_step(cur);
     stage(cur ^ 1, ra, rb);
     __syncthreads();

@@ -5,11 +5,14 @@ SQ_VALU_MFMA_BUSY_CYCLES sums, over all SIMDs, the cycles their matrix pipe is b
 v_mfma_f32_32x32x2_f32: MI355X_MICROARCH.md "Per-instruction cycle constants");
 GRBM_GUI_ACTIVE is summed over the 8 XCDs, so kernel cycles = GRBM_GUI_ACTIVE / 8 and
 
-    MFMA busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles * 1024 SIMDs).
+    MFMA busy fraction (of GRBM cycles) = SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles * 1024 SIMDs).
 
-The clock the chip actually held is kernel cycles / kernel duration; the busy fraction times that
-clock over 2.4 GHz is the fraction of the 157.3 TFLOP/s peak the issued MFMAs amount to (it
-includes the zero-padded K columns and tile tails, which algorithmic FLOPs do not).
+Caveat (MI355X_MICROARCH.md "DVFS give-back"): GRBM_GUI_ACTIVE / 8 / duration reads HIGH on dispatches
+shorter than a few ms -- it gives 2.4-2.5 GHz here while s_memtime / s_memrealtime inside the same
+kernels shows the shader clock held at 2.03 GHz (profiles/r01_conv_trace.txt).  The clock-free number
+is `mfma_busy_cycles_per_simd_per_ns` (= busy GHz): divided by 2.4 it is the fraction of the 157.3 TFLOP/s
+peak the issued MFMAs amount to (padding and tile tails included); divided by the held clock (2.03)
+it is how busy the matrix pipe really is.
 
     python tools/pmc_mfma.py <counter_collection.csv>
 """
@@ -43,8 +46,12 @@ def main():
             continue
         busy = a['mfma_busy'] / (a['cycles'] * SIMDS)
         ghz = a['cycles'] / a['ns']
-        out[k] = {'launches': int(a['launches']), 'total_ms': a['ns'] / 1e6, 'mfma_busy_frac': busy,
-                  'clock_ghz': ghz, 'issued_mfma_frac_of_157.3TF_peak': busy * ghz / 2.4}
+        busy_ghz = a['mfma_busy'] / SIMDS / a['ns']
+        out[k] = {'launches': int(a['launches']), 'total_ms': a['ns'] / 1e6,
+                  'mfma_busy_cycles_per_simd_per_ns': busy_ghz,
+                  'issued_mfma_frac_of_157.3TF_peak': busy_ghz / 2.4,
+                  'mfma_pipe_busy_at_held_clock_2.03GHz': busy_ghz / 2.03,
+                  'grbm_clock_ghz_unreliable_on_short_dispatches': ghz, 'mfma_busy_frac_of_grbm_cycles': busy}
     print(json.dumps(out, indent=1))
 
 

@@ -80,11 +80,12 @@ int main(int argc, char** argv) {
   CK(hipDeviceSynchronize());
   std::vector<unsigned long long> t((size_t)max_tiles * 8);
   CK(hipMemcpy(t.data(), trace, t.size() * 8, hipMemcpyDeviceToHost));
-  double v[5] = {0, 0, 0, 0, 0}, life = 0;
+  double v[5] = {0, 0, 0, 0, 0}, life = 0, cyc = 0;
   unsigned long long tmin = ~0ull, tmax = 0;
   int nb = 0, kind = 0;
   for (int64_t b = 0; b < max_tiles; ++b) if (t[(size_t)b * 8 + 7]) {
-    kind = (int)t[b * 8 + 7];
+    kind = (int)(t[b * 8 + 7] & 255);
+    cyc += (double)(t[b * 8 + 7] >> 8);
     for (int i = 0; i < 5; ++i) v[i] += (double)t[b * 8 + i];
     life += (t[b * 8 + 6] - t[b * 8 + 5]) * 0.01;
     tmin = std::min(tmin, t[b * 8 + 5]); tmax = std::max(tmax, t[b * 8 + 6]);
@@ -116,6 +117,7 @@ int main(int argc, char** argv) {
     for (int c = 0; c < 32; ++c) printf(" %.0f", ec[c] / (nc[c] ? nc[c] : 1));
     printf("\n");
   }
+  if (cyc > 0) printf("shader clock held over the blocks' lives (s_memtime / s_memrealtime): %.3f GHz\n", cyc / (life * 1e3));
   if (kind == 2)
     printf("pipelined kernel: %d blocks, %.2f tiles/block, span %.1f us, mean block life %.1f us; per tile: set-up %.2f us, first loads -> LDS %.2f us, "
            "K-steps %.2f us, hand-over %.2f us\n", nb, v[4] / nb, (tmax - tmin) * 0.01, life / nb, v[0] * 0.01 / v[4], v[1] * 0.01 / v[4],

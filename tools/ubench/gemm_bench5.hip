@@ -136,6 +136,97 @@ __global__ __launch_bounds__(256, MINB) void kdma(const float* A, const float* B
   }
 }
 
+// Hybrid: A (activations: the operand that misses L2) through registers, fetched TWO K-steps ahead with
+// two 8-register sets (= the 16 staging registers the plain loop spends on A + B); B (weights,
+// L2-resident) through LDS-DMA, one step ahead, no registers.  LDS: A padded 2 x 9 KB, B swizzled 2 x 8 KB.
+__global__ __launch_bounds__(256, 4) void khyb(const float* A, const float* B, float* C, int M, int N, int K) {
+  using T = Tile<1, 1>;
+  constexpr int NA = T::NA, NB = T::NB, RP = T::RP;
+  constexpr int ABUF = 64 * LDS_STRIDE, BBUF = 64 * BK;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* ldsA = lds;                    // 2 * ABUF floats
+  float* ldsB = lds + 2 * ABUF;         // 2 * BBUF floats
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wr = T::wave_row(), wc = T::wave_col();
+  const int tiles_n = N / 64;
+  const int KS = K / 32;
+  const int st_off = (tid >> 3) * LDS_STRIDE + (tid & 7) * 4;
+  const int fr_off = (lane & 31) * LDS_STRIDE + 8 * (lane >> 5);
+  const int r = lane & 31, h = lane >> 5, f = dma_swizzle(r);
+  for (int tile = blockIdx.x; tile < (M / 64) * tiles_n; tile += gridDim.x) {
+    const int m0 = (tile / tiles_n) * 64, n0 = (tile % tiles_n) * 64;
+    RowLoader<NA, RP> al(A + (int64_t)m0 * K, M - m0, K);
+    DmaRowLoader<NB, RP> bl(B + (int64_t)n0 * K, N - n0, K);
+    f32x16 acc;
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    f32x4 ra0[NA], ra1[NA];
+    al.load(0, ra0);
+    bl.issue(0, ldsB);
+    if (1 < KS) al.load(1, ra1);
+    for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(ldsA + st_off + i * RP * LDS_STRIDE) = ra0[i];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    auto step = [&](int ks, int cur, f32x4 (&rfree)[NA], f32x4 (&rnext)[NA]) {
+      // rfree: the set whose data (step ks) is already in LDS; rnext holds step ks+1
+      if (ks + 1 < KS) bl.issue(ks + 1, ldsB + (cur ^ 1) * BBUF);
+      if (ks + 2 < KS) al.load(ks + 2, rfree);
+      const float* pa = ldsA + cur * ABUF + (wr * 32) * LDS_STRIDE + fr_off;
+      const float* pb = ldsB + cur * BBUF + (wc * 32 + r) * BK;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int c0 = ((2 * h + 4 * s) ^ f) * 4, c1 = ((2 * h + 4 * s + 1) ^ f) * 4;
+        const f32x4 fa0 = *reinterpret_cast<const f32x4*>(pa + 16 * s), fa1 = *reinterpret_cast<const f32x4*>(pa + 16 * s + 4);
+        const f32x4 fb0 = *reinterpret_cast<const f32x4*>(pb + c0), fb1 = *reinterpret_cast<const f32x4*>(pb + c1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[t], fb0[t], acc, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[t], fb1[t], acc, 0, 0, 0);
+      }
+      if (ks + 1 < KS) {
+        float* wa = ldsA + (cur ^ 1) * ABUF + st_off;
+        // rnext was requested a whole step ago; the loads just issued into rfree (and B's DMA) stay in flight
+        if (ks + 2 < KS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(wa + i * RP * LDS_STRIDE) = rnext[i];
+      }
+      // B's DMA of step ks+1 must have landed before the barrier: it is older than the A loads just issued
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA) : "memory");
+      if (ks + 2 >= KS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    };
+    int ks = 0;
+    while (ks < KS) {
+      step(ks, 0, ra0, ra1);
+      ++ks;
+      if (ks >= KS) break;
+      step(ks, 1, ra1, ra0);
+      ++ks;
+    }
+    float sacc = 0.f;
+    for (int q = 0; q < 16; ++q) sacc += acc[q];
+    C[(int64_t)tile * 256 + tid] = sacc;
+    __syncthreads();
+  }
+}
+
+static void run_hyb(const char* name, const float* A, const float* B, float* C, int M, int N, int K) {
+  const int lds = (2 * 64 * LDS_STRIDE + 2 * 64 * BK) * 4;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(khyb), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(khyb, dim3(1024), dim3(256), lds, 0, A, B, C, M, N, K);
+  CK(hipEventRecord(e0));
+  const int reps = 10;
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(khyb, dim3(1024), dim3(256), lds, 0, A, B, C, M, N, K);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= reps;
+  printf("%-46s %8.3f ms  %6.1f TFLOP/s (%.1f %% of 157.3)\n", name, ms, 2.0 * M * N * K / ms / 1e9, 2.0 * M * N * K / ms / 1e9 / 1.573);
+}
+
 template <int NST, int MINB>
 static void run_dma(const char* name, const float* A, const float* B, float* C, int M, int N, int K) {
   auto kern = kdma<NST, MINB>;
@@ -189,6 +280,7 @@ int main(int argc, char** argv) {
     printf("-- pass %d\n", pass);
     run<0>("full loop (register staging, 4 blocks/CU)", A, B, C, M, N, K);
     run<16>("  + fragment reads up front", A, B, C, M, N, K);
+    run_hyb("hybrid: A regs 2 steps ahead + B LDS-DMA", A, B, C, M, N, K);
     run_dma<2, 4>("LDS-DMA, 2 stages, 4 blocks/CU", A, B, C, M, N, K);
     run_dma<2, 3>("LDS-DMA, 2 stages, 3 blocks/CU", A, B, C, M, N, K);
     run_dma<3, 3>("LDS-DMA, 3 stages, 3 blocks/CU", A, B, C, M, N, K);
