@@ -290,6 +290,8 @@ def main():
                 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': measured_traffic(args.workload, batch),
                 'traffic_unit': 'HBM bytes per forward (rocprofv3 PMC, profiles/)',
+                'clock_note': 'peak is the 2.4 GHz figure; s_memtime/s_memrealtime inside these kernels shows the chip '
+                              'holding 2.03 GHz under this load (profiles/r01_conv_trace.txt), i.e. 133 TFLOP/s',
                 'algorithmic_flops_per_forward': flops_embed,
                 'forward_ms_hip_events': embed_ms,
                 'conv_only': {'ms': conv_ms, 'tflops': conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms else None},
