@@ -32,6 +32,7 @@
 
 #include <stdlib.h>
 
+#include <atomic>
 #include <type_traits>
 
 namespace dif {
@@ -565,8 +566,35 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const 
               }
         } else {
           // the partner never showed up (not co-resident): compute its K range here instead of
-          // waiting for ever -- slower, still correct
+          // waiting for ever -- slower, still correct, and the SAME bits: the range is accumulated
+          // from zero, exactly like the partner's slab, and added to this block's partial, which
+          // waits in the block's private stash slab meanwhile (sk_slab holds 2 * P slabs)
+          float* stash = a.sk_slab + ((int64_t)P + p) * SLAB;
+#pragma unroll
+          for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int n = 0; n < WN; ++n)
+#pragma unroll
+              for (int r4 = 0; r4 < 4; ++r4) {
+                f32x4 v = {acc[m][n][4 * r4], acc[m][n][4 * r4 + 1], acc[m][n][4 * r4 + 2], acc[m][n][4 * r4 + 3]};
+                *reinterpret_cast<f32x4*>(stash + (((m * WN + n) * 4 + r4) * T::NT + tid) * 4) = v;
+              }
+          zero_acc<T>(acc);
           run(q_kb, q_ke, false);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // own stores are in L2; drop any stale L1 line
+#pragma unroll
+          for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int n = 0; n < WN; ++n)
+#pragma unroll
+              for (int r4 = 0; r4 < 4; ++r4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(stash + (((m * WN + n) * 4 + r4) * T::NT + tid) * 4);
+                acc[m][n][4 * r4] = v[0] + acc[m][n][4 * r4];
+                acc[m][n][4 * r4 + 1] = v[1] + acc[m][n][4 * r4 + 1];
+                acc[m][n][4 * r4 + 2] = v[2] + acc[m][n][4 * r4 + 2];
+                acc[m][n][4 * r4 + 3] = v[3] + acc[m][n][4 * r4 + 3];
+              }
         }
         kdone = q_ke;
       }
@@ -817,21 +845,42 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_pipe_kernel(const C
   epi_pre(std::integral_constant<int, 7>()); epi_post(std::integral_constant<int, 7>());
 }
 
-static int g_num_cus = 0;
+// Per-device launch state.  One process drives one GPU by convention, but nothing here depends on it:
+// the CU count and the "dynamic LDS limit raised" bit of every kernel are cached per device ordinal.
+constexpr int kMaxDevices = 64;
+
+static int cur_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+  return dev;
+}
 
 static int num_cus() {
-  if (g_num_cus == 0) {
-    int dev = 0;
+  static std::atomic<int> cus[kMaxDevices];
+  const int dev = cur_device();
+  int c = cus[dev].load(std::memory_order_relaxed);
+  if (c == 0) {
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      g_num_cus = prop.multiProcessorCount;
-    if (g_num_cus <= 0) g_num_cus = 256;
+    c = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 0;
+    if (c <= 0) c = 256;
+    cus[dev].store(c, std::memory_order_relaxed);
   }
-  return g_num_cus;
+  return c;
+}
+
+template <class K>
+static int allow_dynamic_lds(K kern, int bytes) {
+  static std::atomic<unsigned char> done[kMaxDevices];   // one array per kernel instantiation
+  const int dev = cur_device();
+  if (!done[dev].load(std::memory_order_acquire)) {
+    DIF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done[dev].store(1, std::memory_order_release);
+  }
+  return 0;
 }
 
 int conv_max_blocks() { return 4 * num_cus(); }
-size_t conv_slab_floats() { return 128 * 128; }
+size_t conv_slab_floats() { return 2 * 64 * 64; }   // per block: the published partial + the fallback stash (64x64 tile)
 
 template <class T, bool PRE, bool DMA, int AM>
 static int launch_conv_pre(const ConvArgs& a, hipStream_t st);
@@ -840,13 +889,9 @@ static int launch_conv_pre(const ConvArgs& a, hipStream_t st);
 // software-pipelined kernel.  Returns 1 when it does not apply (the caller falls through).
 template <class T, bool PRE, int AM, int CPS = 1>
 static int launch_conv_pipe(const ConvArgs& a, hipStream_t st) {
-  static bool attr_set = false;
   auto kern = conv_pipe_kernel<T, PRE, AM, CPS>;
   constexpr int lds = T::LDS_BYTES;
-  if (!attr_set) {
-    DIF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_set = true;
-  }
+  if (allow_dynamic_lds(kern, lds)) return -1;
   const int64_t tiles = ((a.M + T::BM - 1) / T::BM) * (int64_t)((a.Cout + T::BN - 1) / T::BN);
   int64_t slots = 4 * (int64_t)num_cus();
   if (slots > a.sk_max_blocks) slots = a.sk_max_blocks;
@@ -867,10 +912,9 @@ static int launch_conv_pipe(const ConvArgs& a, hipStream_t st) {
 }
 
 static bool pipe_applies(const ConvArgs& a, int64_t tiles, int KS, int64_t slots) {
-  const char* e = getenv("DIF_PIPE");     // read per launch: tests compare both paths inside one process
-  const int use_pipe = e ? atoi(e) : 1;
   static const int sk_min_ks = getenv("DIF_SK_MIN_KS") ? atoi(getenv("DIF_SK_MIN_KS")) : 32;
-  if (!use_pipe) return false;
+  if (!a.use_pipe) return false;                                      // dif_net_set_option("pipe", 0)
+  if (slots < 8) return false;                                        // the kernel deals tiles out per XCD (8 of them)
   if (KS >= sk_min_ks && tiles < 8 * slots) return false;           // long K, few tiles: stream-K's case
   if (tiles < slots + slots / 2) return false;                        // fewer than ~1.5 tiles per block: nothing to overlap
   if (a.act == ACT_RELU6 || a.act2 == ACT_RELU6) return false;        // its epilogue knows slopes, not clamps
@@ -916,13 +960,8 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
 
 template <class T, bool PRE, bool DMA, int AM>
 static int launch_conv_pre(const ConvArgs& a, hipStream_t st) {
-  static bool attr_set = false;
   auto kern = conv_igemm_kernel<T, PRE, DMA, AM>;
-  if (!attr_set) {
-    DIF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                T::LDS_BYTES));
-    attr_set = true;
-  }
+  if (allow_dynamic_lds(kern, T::LDS_BYTES)) return -1;
   const int64_t tiles = ((a.M + T::BM - 1) / T::BM) * (int64_t)((a.Cout + T::BN - 1) / T::BN);
   const int KS = a.Kpad / BK;
   const int64_t I = tiles * KS;
@@ -962,22 +1001,11 @@ static int launch_conv_pre(const ConvArgs& a, hipStream_t st) {
   return 0;
 }
 
-int conv_tile_choice(int64_t M, int Cout, int Kpad) {
-  // 0: 128x128, 1: 128x64, 2: 64x128, 3: 64x64
-  static const int forced = getenv("DIF_CONV_TILE") ? atoi(getenv("DIF_CONV_TILE")) : -1;
-  if (forced >= 0) return (Cout <= 64 && (forced == 0 || forced == 2)) ? forced + 1 : forced;
-  (void)M;
-  (void)Cout;
-  (void)Kpad;
-  // Measured on MI355X (tools/layer_profile.py with DIF_CONV_TILE=0..3, both networks at
-  // batch 256): the 64x64 tile wins or ties on every layer class -- four blocks per CU keep
-  // the MFMA pipe fed across each block's barriers, prologue and epilogue, and the hardware
-  // dispatcher balances the many small tiles; the larger tiles only tie on the long-K,
-  // wide-N layers.  The larger shapes stay available for experiments (DIF_CONV_TILE).
-  return 3;
-}
-
-int conv_run(const ConvArgs& a, int tile, hipStream_t st) {
+// One tile shape ships: 64x64 (four blocks per CU).  Measured per layer over both networks in round 1
+// against 128x128 / 128x64 / 64x128: it wins or ties everywhere (four co-resident blocks keep the MFMA pipe
+// fed across each block's barriers, prologue and epilogue; the larger tiles spilled at the register budget
+// of two blocks per CU), so the other instantiations were dropped from the library.
+int conv_run(const ConvArgs& a, hipStream_t st) {
   if (a.M <= 0) return 0;
   if (a.Cin % 4 != 0) return set_error("conv: Cin must be a multiple of 4 (got %d)", a.Cin);
   if (a.Cout % 4 != 0) {
@@ -997,13 +1025,7 @@ int conv_run(const ConvArgs& a, int tile, hipStream_t st) {
     if (span * a.H * a.W * a.Cin * 4 >= 0x7fffffffLL)
       return set_error("conv: a 256-pixel tile spans more than 2 GiB of input (%dx%dx%d)", a.H, a.W, a.Cin);
   }
-  if (tile < 0) tile = conv_tile_choice(a.M, a.Cout, a.Kpad);
-  switch (tile) {
-    case 0: return launch_conv<Tile<2, 2>>(a, st);
-    case 1: return launch_conv<Tile<2, 1>>(a, st);
-    case 2: return launch_conv<Tile<1, 2>>(a, st);
-    default: return launch_conv<Tile<1, 1>>(a, st);
-  }
+  return launch_conv<Tile<1, 1>>(a, st);
 }
 
 }  // namespace dif

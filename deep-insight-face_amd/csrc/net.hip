@@ -931,6 +931,7 @@ int Net::finalize(int mb) {
   }
   sk_max_blocks = conv_max_blocks();
   if (const char* e = getenv("DIF_SK_SPIN_LIMIT")) sk_spin_limit = atoi(e);   // test hook (tests/test_embed_gpu.py)
+  if (const char* e = getenv("DIF_PIPE")) use_pipe = atoi(e) != 0;              // read once here, never per launch
   // Two lanes pay off when the kernels are long enough for one lane's tail to hide under the other
   // lane's head (IResNet-100 at batch 256: +4 %); with many short launches (ResNet50V2: -1 %) the
   // half-size launches only fill the chip worse.  Default: two lanes from 10 GFLOP per launch per lane.
@@ -959,6 +960,10 @@ int Net::finalize(int mb) {
     L.sk_flag = static_cast<unsigned*>(d);
     DIF_HIP(hipMemset(L.sk_flag, 0, (size_t)sk_max_blocks * sizeof(unsigned)));
     L.sk_epoch = 0;
+    // persistent-grid size of this lane's stream-K launches.  DIF_SK_LANE_SPLIT=1 gives each lane 1/nl of the
+    // chip's resident slots, so the lanes' grids are co-resident instead of queueing behind each other
+    static const int lane_split = getenv("DIF_SK_LANE_SPLIT") ? atoi(getenv("DIF_SK_LANE_SPLIT")) : 0;
+    L.sk_max_blocks = (lane_split && nl > 1) ? sk_max_blocks / nl : sk_max_blocks;
 
     L.bufs.assign(buf_elems.size(), nullptr);
     for (size_t b = 0; b < buf_elems.size(); ++b) {
@@ -984,12 +989,7 @@ const char* Net::kernel_name(const Op& op, int n) const {
     case OP_ZERO: return "memset";
     case OP_UPSAMPLE: return "upsample2_kernel";
     case OP_COPY: return "copy_to_view_kernel";
-    case OP_CONV: {
-      const TensorDesc& yd = tensors[op.y >= 0 ? op.y : op.y2];
-      static const char* names[4] = {"conv_igemm_kernel<128x128>", "conv_igemm_kernel<128x64>",
-                                     "conv_igemm_kernel<64x128>", "conv_igemm_kernel<64x64>"};
-      return names[conv_tile_choice((int64_t)n * yd.H * yd.W, op.Cout, (op.KH * op.KW * op.Cin + 31) / 32 * 32)];
-    }
+    case OP_CONV: return "conv_igemm_kernel<64x64>";   // or its software-pipelined sibling conv_pipe_kernel (conv.hip)
   }
   return "?";
 }
@@ -1084,10 +1084,11 @@ int Net::run_op(const Op& op, Lane& L, const void* xin, int n, int layout, int d
       }
       a.sk_slab = L.sk_slab;
       a.sk_flag = L.sk_flag;
-      a.sk_max_blocks = sk_max_blocks;
+      a.sk_max_blocks = L.sk_max_blocks;
       a.sk_epoch = ++L.sk_epoch;
       a.sk_spin_limit = sk_spin_limit;
-      if (conv_run(a, -1, st)) return -1;
+      a.use_pipe = use_pipe;
+      if (conv_run(a, st)) return -1;
       break;
     }
     case OP_MAXPOOL: {

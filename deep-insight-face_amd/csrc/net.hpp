@@ -111,12 +111,14 @@ struct Net {
     float* sk_slab = nullptr;
     unsigned* sk_flag = nullptr;
     unsigned sk_epoch = 0;
+    int sk_max_blocks = 0;
   };
   std::vector<Lane> lanes;
   hipEvent_t ev_start = nullptr;
   std::vector<int64_t> buf_elems;   // per image
   int sk_max_blocks = 0;
   int sk_spin_limit = 1 << 18;
+  int use_pipe = 1;                 // option "pipe": 0 keeps every convolution on conv_igemm_kernel
 
   ~Net();
   int build();                       // dispatch on arch/head

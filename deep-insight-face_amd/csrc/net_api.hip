@@ -91,6 +91,15 @@ int dif_net_finalize(dif_net* h, int max_batch) {
   return h->net.finalize(max_batch);
 }
 
+int dif_net_set_option(dif_net* h, const char* key, int value) {
+  if (!h || !key) return set_error("dif_net_set_option: null argument");
+  if (!strcmp(key, "pipe")) {
+    h->net.use_pipe = value != 0;
+    return 0;
+  }
+  return set_error("dif_net_set_option: unknown option '%s'", key);
+}
+
 int dif_net_output_dim(const dif_net* h, int64_t shape[3]) {
   if (!h || !shape) return set_error("dif_net_output_dim: null argument");
   const TensorDesc& t = h->net.tensors[h->net.output_tensor];

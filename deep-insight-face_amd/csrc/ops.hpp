@@ -77,6 +77,7 @@ struct ConvArgs {
   int sk_max_blocks;
   int sk_skew_q16;      // stream-K share skew by resident slot, Q16 (conv.hip: sk_begin); filled by conv_run
   int sk_spin_limit;    // polls before the owner computes a missing K range itself; < 0: always (test hook)
+  int use_pipe;         // 0: never take the software-pipelined kernel (Net option "pipe"; tests compare both paths)
   int dbg;              // development aid: bit 0 drops the pipelined kernel's stores, bit 1 its shortcut loads
   // development aid (tools/ubench/conv_trace.hip), null in the library: 4 x u64 per hardware block =
   // s_memrealtime (100 MHz) at entry / after the first mainloop / at exit, and the HW_ID register
@@ -87,8 +88,7 @@ struct ConvArgs {
 
 int conv_max_blocks();        // persistent blocks the kernel may use on this device
 size_t conv_slab_floats();    // floats per slab
-int conv_tile_choice(int64_t M, int Cout, int Kpad);
-int conv_run(const ConvArgs& a, int tile, hipStream_t st);
+int conv_run(const ConvArgs& a, hipStream_t st);
 
 enum { POOL_MAX = 0, POOL_L2 = 1, POOL_AVG = 2 };
 struct PoolArgs {

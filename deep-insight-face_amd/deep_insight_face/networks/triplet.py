@@ -96,6 +96,10 @@ class DifEmbedder:
         self._transform = (float(scale), tuple(float(v) for v in bias), bool(bgr), bool(hflip))
         N.check(N.lib.dif_net_set_input_transform(self._h, float(scale), b, int(bool(bgr)) | (2 if hflip else 0)))
 
+    def set_option(self, key, value):
+        """Execution option of the library (include/dif.h: dif_net_set_option), e.g. ``('pipe', 0)``."""
+        N.check(N.lib.dif_net_set_option(self._h, key.encode(), int(value)), ValueError)
+
     def embed_flipped_concat(self, x, layout=None):
         """[embed(x), embed(mirror(x))] concatenated along the feature axis -> [N, 2*emd]: the
         ``use_flipped_images`` option of the evaluation entry point (scripts/insight_face.py:117-118,
@@ -171,6 +175,15 @@ class DifEmbedder:
                 off += c * sz
         return outs
 
+    def op_table(self):
+        """The static launch list of one forward: (op name, kernel name, MACs per image) per launch."""
+        rows = []
+        name, kern, macs = ctypes.c_char_p(), ctypes.c_char_p(), ctypes.c_double()
+        for i in range(N.lib.dif_net_launch_count(self._h)):
+            N.check(N.lib.dif_net_op_info(self._h, i, ctypes.byref(name), ctypes.byref(kern), ctypes.byref(macs)))
+            rows.append((name.value.decode(), kern.value.decode(), macs.value))
+        return rows
+
     def profile(self, x):
         """Per-launch milliseconds of one forward of a CUDA uint8/float batch (diagnostic):
         list of (op name, kernel name, MACs per image, ms)."""
@@ -186,12 +199,7 @@ class DifEmbedder:
         k = N.lib.dif_net_launch_count(self._h)
         ms = (ctypes.c_float * k)()
         N.check(N.lib.dif_net_embed_profile(self._h, N.ptr(t), n, layout, dtype, N.ptr(out), N.stream_ptr(), ms))
-        rows = []
-        name, kern, macs = ctypes.c_char_p(), ctypes.c_char_p(), ctypes.c_double()
-        for i in range(k):
-            N.check(N.lib.dif_net_op_info(self._h, i, ctypes.byref(name), ctypes.byref(kern), ctypes.byref(macs)))
-            rows.append((name.value.decode(), kern.value.decode(), macs.value, float(ms[i])))
-        return rows
+        return [(n, kn, m, float(ms[i])) for i, (n, kn, m) in enumerate(self.op_table())]
 
     def predict_on_batch(self, x):
         """NumPy in -> NumPy float32 out (Keras semantics); torch in -> CUDA tensor out."""

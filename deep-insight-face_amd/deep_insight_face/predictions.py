@@ -56,6 +56,11 @@ class encoding_base:
         return np.stack([_resize(im, tuple(self.img_size)) for im in images])
 
 
+def _saved_transform(model):
+    """(scale, bias, bgr, hflip) currently set on a shared model, so a wrapper can put it back."""
+    return getattr(model, '_transform', (1.0, (0.0, 0.0, 0.0), False, False))
+
+
 class TripletPrediction(encoding_base):
     def __init__(self, emd_model, img_size=(96, 96)):
         assert len(img_size) == 2, "Invalid Image size format"
@@ -63,11 +68,12 @@ class TripletPrediction(encoding_base):
 
     def _embedding_batch(self, images, rescale: float = 1 / 255.) -> np.ndarray:
         batch = self._prep(images)
+        saved = _saved_transform(self.emd_model)
         self.emd_model.set_input_transform(scale=rescale)
         try:
             return self.emd_model.predict_on_batch(batch)
         finally:
-            self.emd_model.set_input_transform()
+            self.emd_model.set_input_transform(*saved)        # the caller's transform, not the identity
 
     def _embedding(self, image: np.ndarray, rescale: float = 1 / 255.) -> np.ndarray:
         assert isinstance(image, np.ndarray), "Invalid image format, should be of type numpy array"
@@ -95,11 +101,12 @@ class SiamesePrediction(encoding_base):
 
     def _embedding_batch(self, images, rescale: float = 1 / 255.) -> np.ndarray:
         batch = self._prep(images)
+        saved = _saved_transform(self.emd_model)
         self.emd_model.set_input_transform(scale=rescale, bias=tuple(-m for m in _VGG_MEAN_BGR), bgr=True)
         try:
             return self.emd_model.predict_on_batch(batch)
         finally:
-            self.emd_model.set_input_transform()
+            self.emd_model.set_input_transform(*saved)
 
     def _embedding(self, image: np.ndarray, rescale: float = 1 / 255.) -> np.ndarray:
         assert isinstance(image, np.ndarray), "Invalid image format, should be of type numpy array"

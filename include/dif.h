@@ -140,6 +140,10 @@ int dif_net_get_param(const dif_net* net, const char* name, float* data_host, in
 int dif_net_set_input_transform(dif_net* net, float scale, const float bias[3], int flags);
 /* pack weights for the kernels, upload, and size the activation workspace */
 int dif_net_finalize(dif_net* net, int max_batch);
+/* execution options (no reference counterpart: Keras picks its kernels by itself).  Keys:
+ *   "pipe"  1 (default) lets short-K convolutions take the software-pipelined kernel, 0 keeps every
+ *           convolution on the plain implicit-GEMM kernel (the two are compared by the parity tests) */
+int dif_net_set_option(dif_net* net, const char* key, int value);
 int dif_net_output_dim(const dif_net* net, int64_t shape[3]); /* {emd,1,1} or {C,H,W} for v3 */
 /* networks with several outputs (arch "yolov3": the three detection maps, coarse first; emd_size
  * carries the class count): out_dev then holds output 0 for all n images, then output 1, ... */

@@ -1,7 +1,12 @@
 """Independent torch-CPU (NCHW, torch.nn.functional) implementation of the embedding
-networks, used to cross-check the NumPy oracle (oracle/nets.py is "parity unpinned":
-no reference arithmetic exists for the backbones, so two independently written
-implementations must agree).  Not the reference, not the product."""
+networks.  TEST INFRASTRUCTURE ONLY (see oracle/__init__.py); **PARITY UNPINNED** like
+oracle/nets.py.  Two uses:
+  * cross-check of the NumPy oracle (no reference arithmetic exists for the backbones, so two
+    independently written implementations must agree): tests/test_oracle_nets.py;
+  * bench.py's ``cpu_baseline``: SURVEY.md section 8(d) / BASELINE.md section 3 name torch-CPU ops
+    with all host threads as the CPU stand-in for the reference's TF2/Keras CPU path
+    (predictions.py:152-156 -> networks/triplet.py:119-141), which cannot run here.
+Not the reference, not the product."""
 import torch
 import torch.nn.functional as F
 

@@ -110,7 +110,7 @@ def test_yolov3_structure_matches_the_cfg():
 
 
 def test_yolov3_oracle_vs_torch():
-    import torch_ref
+    from oracle import torch_nets as torch_ref
     p = _yolo_params()
     x = _frames(1, 96)
     a = odet.yolov3_forward(x, p)

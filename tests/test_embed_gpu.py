@@ -252,12 +252,12 @@ def test_pipelined_kernel_equals_plain_kernel(cuda, monkeypatch):
         x = torch.from_numpy(rng.integers(0, 256, (n,) + shape, dtype=np.uint8)).cuda()
         m = DifEmbedder(arch, head, emd, shape, max_batch=n).init_synthetic(5)
         m.set_input_transform(scale=1 / 255.)
-        monkeypatch.setenv('DIF_PIPE', '1')
+        m.set_option('pipe', 1)
         a = m.embed(x)
         a2 = m.embed(x)
-        monkeypatch.setenv('DIF_PIPE', '0')
+        m.set_option('pipe', 0)
         b = m.embed(x)
-        monkeypatch.delenv('DIF_PIPE')
+        m.set_option('pipe', 1)
         a, a2, b = [t if isinstance(t, list) else [t] for t in (a, a2, b)]
         for ta, ta2, tb in zip(a, a2, b):
             assert torch.equal(ta, ta2)                                   # deterministic

@@ -4,7 +4,7 @@ the oracle (GPU)."""
 import numpy as np
 import pytest
 
-import torch_ref
+from oracle import torch_nets as torch_ref
 from oracle import nets
 
 

@@ -1,10 +1,10 @@
 """The NumPy oracle of the embedding networks against an independently written
-torch-CPU implementation (tests/torch_ref.py), plus shape / parameter-count facts from
+torch-CPU implementation (oracle/torch_nets.py), plus shape / parameter-count facts from
 the public model definitions, plus the library's parameter table.  No GPU."""
 import numpy as np
 import pytest
 
-import torch_ref
+from oracle import torch_nets as torch_ref
 from oracle import nets
 
 

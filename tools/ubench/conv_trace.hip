@@ -42,6 +42,7 @@ int main(int argc, char** argv) {
   CK(hipMemset(sh, 0, hv.size() * 4));
   dif::ConvArgs a;
   memset(&a, 0, sizeof(a));
+  a.use_pipe = 1;
   a.x = x; a.w = w; a.y = y; a.scale = sc; a.shift = sh; a.res = res ? r : nullptr;
   if (pre) { a.pre_scale = sc; a.pre_shift = sh; a.pre_act = dif::ACT_RELU; }
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.KH = a.KW = K; a.stride = stride;
@@ -52,12 +53,12 @@ int main(int argc, char** argv) {
 
   unsigned epoch = 0;
   hipStream_t st = nullptr;
-  for (int i = 0; i < 5; ++i) { a.sk_epoch = ++epoch; if (dif::conv_run(a, -1, st)) { printf("conv_run failed\n"); return 1; } }
+  for (int i = 0; i < 5; ++i) { a.sk_epoch = ++epoch; if (dif::conv_run(a, st)) { printf("conv_run failed\n"); return 1; } }
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const int reps = 20;
   CK(hipEventRecord(e0, st));
-  for (int i = 0; i < reps; ++i) { a.sk_epoch = ++epoch; dif::conv_run(a, -1, st); }
+  for (int i = 0; i < reps; ++i) { a.sk_epoch = ++epoch; dif::conv_run(a, st); }
   CK(hipEventRecord(e1, st));
   CK(hipEventSynchronize(e1));
   float ms;
@@ -76,7 +77,7 @@ int main(int argc, char** argv) {
   // traced run
   CK(hipMemset(trace, 0, (size_t)max_tiles * 64));
   a.trace = trace; a.sk_epoch = ++epoch;
-  dif::conv_run(a, -1, st);
+  dif::conv_run(a, st);
   CK(hipDeviceSynchronize());
   std::vector<unsigned long long> t((size_t)max_tiles * 8);
   CK(hipMemcpy(t.data(), trace, t.size() * 8, hipMemcpyDeviceToHost));
