@@ -100,6 +100,49 @@ def cpu_model_string():
     return platform.processor() or platform.machine()
 
 
+def usable_cores():
+    """Host threads this process can really run: the affinity mask, cut by the cgroup CPU quota
+    (a GPU box hands a job a share of the host, e.g. 16 of 256 hardware threads), then confirmed by
+    timing one convolution at the candidate counts -- an oversubscribed torch/OpenMP pool is 10-100x
+    slower than a fitting one, which would make the baseline a straw man."""
+    import torch.nn.functional as F
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        q, p = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            quota = int(q) / int(p)
+    except (OSError, ValueError):
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            p = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                quota = q / p
+        except (OSError, ValueError):
+            pass
+    if quota:
+        n = max(1, min(n, int(quota + 0.5)))
+    x = torch.randn(8, 256, 14, 14)
+    w = torch.randn(256, 256, 3, 3)
+    best, best_t = n, None
+    c = n
+    while c >= 4:
+        torch.set_num_threads(c)
+        F.conv2d(x, w, padding=1)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            F.conv2d(x, w, padding=1)
+        t = time.perf_counter() - t0
+        if best_t is None or t < 0.9 * best_t:
+            best, best_t = c, t
+        c //= 2
+    return best, quota
+
+
 def cpu_baseline(arch, head, gallery_rows, budget_s=12.0):
     """CPU stand-in for the reference's TF2/Keras CPU path (which cannot run here: SURVEY 8(c)), as
     SURVEY 8(d) / BASELINE.md section 3 specify it:
@@ -113,12 +156,13 @@ def cpu_baseline(arch, head, gallery_rows, budget_s=12.0):
     from oracle import distance as od
     from oracle import nets, torch_nets
     from deep_insight_face.networks.weights import synth_params
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except (AttributeError, OSError):
-        pass
+    cores, quota = usable_cores()
     torch.set_num_threads(cores)
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(cores)                              # the NumPy/BLAS legs run on the same threads
+    except Exception:
+        pass
     p = synth_params(nets.model_spec(arch, 512, 112, head))
     rng = np.random.default_rng(1234)
 
@@ -153,7 +197,7 @@ def cpu_baseline(arch, head, gallery_rows, budget_s=12.0):
     embed_rate, match_rate, blas_rate = sample / t_embed, probes / t_match, sample / t_blas
     return {
         'value': 1.0 / (1.0 / embed_rate + 1.0 / match_rate), 'unit': 'faces/s', 'cores': cores, 'kind': 'port',
-        'cpu_model': cpu_model_string(),
+        'cpu_model': cpu_model_string(), 'host_hw_threads': os.cpu_count(), 'cgroup_cpu_quota': quota,
         'sample': '%d faces through torch-CPU ops on %d threads (%.2fs) + reference-formula match of %d probes vs '
                   '%d rows (%.2fs); value = 1/(1/embed_rate + 1/match_rate)' % (sample, cores, t_embed, probes,
                                                                                gallery_rows, t_match),

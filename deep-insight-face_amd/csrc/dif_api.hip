@@ -47,7 +47,7 @@ int dif_device_count(void) {
 
 int dif_pairwise(const float* e1_dev, int64_t n1, const float* e2_dev, int64_t n2, int d, int metric,
                  float* out_dev, void* stream) {
-  if (check_metric(metric)) return -1;
+  if (metric != DIF_METRIC_SIMILARITY && check_metric(metric)) return -1;
   if (d <= 0) return set_error("dif_pairwise: d must be positive (got %d)", d);
   if (n1 < 0 || n2 < 0) return set_error("dif_pairwise: negative row count");
   if (n1 != n2 && n1 != 1 && n2 != 1)
@@ -75,8 +75,9 @@ int dif_gallery_destroy(dif_gallery* h) {
   if (g.rows) (void)hipFree(g.rows);
   if (g.sq) (void)hipFree(g.sq);
   if (g.ninv) (void)hipFree(g.ninv);
-  if (g.part_key) (void)hipFree(g.part_key);
-  if (g.part_idx) (void)hipFree(g.part_idx);
+  for (void* p : {(void*)g.part_key, (void*)g.part_cnt, (void*)g.part_idx, (void*)g.eps, (void*)g.best,
+                  (void*)g.best_dist, (void*)g.flagged, (void*)g.nflag, (void*)g.sqmax_bits})
+    if (p) (void)hipFree(p);
   delete h;
   return 0;
 }
@@ -125,7 +126,19 @@ int dif_match_merge(const float* keys_dev, const int64_t* idx_dev, const float* 
   if (n == 0) return 0;
   if (!keys_dev || !idx_dev || !dist_dev || !idx_out_dev || !dist_out_dev)
     return set_error("dif_match_merge: null pointer");
-  return match_merge_run(keys_dev, idx_dev, dist_dev, R, n, idx_out_dev, dist_out_dev, (hipStream_t)stream);
+  return match_merge_run(keys_dev, (int64_t)n * 4, idx_dev, (int64_t)n * 8, dist_dev, (int64_t)n * 4, R, n, idx_out_dev,
+                         dist_out_dev, (hipStream_t)stream);
+}
+
+int dif_match_merge_packed(const void* packed_dev, int R, int n, int64_t* idx_out_dev, float* dist_out_dev,
+                           void* stream) {
+  if (R <= 0 || n < 0) return set_error("dif_match_merge_packed: bad sizes R=%d n=%d", R, n);
+  if (n == 0) return 0;
+  if (!packed_dev || !idx_out_dev || !dist_out_dev) return set_error("dif_match_merge_packed: null pointer");
+  const char* base = static_cast<const char*>(packed_dev);
+  const int64_t pitch = (int64_t)n * 16;     // per rank: key[n] f32 | dist[n] f32 | idx[n] i64
+  return match_merge_run(base, pitch, base + (size_t)n * 8, pitch, base + (size_t)n * 4, pitch, R, n, idx_out_dev,
+                         dist_out_dev, (hipStream_t)stream);
 }
 
 }  // extern "C"

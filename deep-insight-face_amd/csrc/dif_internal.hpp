@@ -24,9 +24,19 @@ struct Gallery {
   float* rows = nullptr;    // [n][d]
   float* sq = nullptr;      // |g|^2
   float* ninv = nullptr;    // -1/|g|
+  // match workspace (csrc/match.hip): per (block, probe) minimum key, candidate count, candidate rows
   float* part_key = nullptr;
+  int* part_cnt = nullptr;
   int* part_idx = nullptr;
   size_t part_cap = 0;
+  // per probe: error bound of the search key, packed (key, index) winner, its distance, overflow list
+  float* eps = nullptr;
+  unsigned long long* best = nullptr;
+  float* best_dist = nullptr;
+  int* flagged = nullptr;
+  size_t probe_cap = 0;
+  int* nflag = nullptr;            // number of probes sent to the exact search in the current call
+  unsigned* sqmax_bits = nullptr;  // bits of max |g|^2 over the rows
 };
 
 int gallery_norms(Gallery* g, hipStream_t st);
@@ -34,7 +44,7 @@ int match_run(Gallery* g, const float* probes, int B, int metric, int64_t* idx_o
               float* key_out, hipStream_t st);
 int pairwise_run(const float* e1, int64_t n1, const float* e2, int64_t n2, int D, int metric, float* out,
                  hipStream_t st);
-int match_merge_run(const float* keys, const int64_t* idx, const float* dist, int R, int B, int64_t* idx_out,
-                    float* dist_out, hipStream_t st);
+int match_merge_run(const void* keys, int64_t key_pitch, const void* idx, int64_t idx_pitch, const void* dist,
+                    int64_t dist_pitch, int R, int B, int64_t* idx_out, float* dist_out, hipStream_t st);   // pitches in bytes
 
 }  // namespace dif

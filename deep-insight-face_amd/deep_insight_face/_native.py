@@ -44,6 +44,7 @@ SIGNATURES = {
     'dif_gallery_size': (c_int64, [c_void_p]),
     'dif_match': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dif_match_merge': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'dif_match_merge_packed': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'dif_net_create': (c_int, [P(c_void_p), c_char_p, c_char_p, c_int, c_int, c_int]),
     'dif_net_destroy': (c_int, [c_void_p]),
     'dif_net_param_count': (c_int, [c_void_p]),
@@ -72,7 +73,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-METRIC_SQL2, METRIC_COSINE = 0, 1
+METRIC_SQL2, METRIC_COSINE, METRIC_SIMILARITY = 0, 1, 2
 LAYOUT_NHWC, LAYOUT_NCHW = 0, 1
 DTYPE_F32, DTYPE_U8 = 0, 1
 

@@ -41,6 +41,19 @@ class Gallery:
     def __len__(self):
         return int(N.lib.dif_gallery_size(self._h))
 
+    def match_into(self, probes, distance_metric, idx, dist, key=None):
+        """Allocation-free form for a serving loop: `probes` [B, d] float32 CUDA, results written into the
+        caller's CUDA tensors idx [B] int64, dist [B] float32 and (optional) key [B] float32 -- which may be
+        slices of one packed buffer (see ShardedGallery)."""
+        if distance_metric not in (0, 1):
+            raise RuntimeError('Undefined distance metric %d' % distance_metric)
+        B = probes.shape[0]
+        if B:
+            if len(self) == 0:
+                raise ValueError('attempt to get argmin of an empty sequence')
+            N.check(N.lib.dif_match(self._h, N.ptr(probes), B, distance_metric, N.ptr(idx), N.ptr(dist),
+                                    N.ptr(key) if key is not None else None, N.stream_ptr()))
+
     def match(self, probes, distance_metric=1, return_key=False):
         """-> (idx[B] int64, dist[B] float32) [, key[B]]; NumPy in -> NumPy out."""
         if distance_metric not in (0, 1):

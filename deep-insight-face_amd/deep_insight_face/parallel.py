@@ -7,8 +7,8 @@ for the exchange (backend "nccl" is RCCL over xGMI on ROCm; "gloo" on CPU for te
   1. every rank embeds its own slice of the batch                    [b, d]
   2. ONE all-gather of the per-rank embeddings                       [R*b, d]   (8 MiB at B=4096)
   3. every rank matches ALL probes against ITS gallery shard         (key, idx, dist)[R*b]
-  4. ONE all-gather of the packed per-rank results                   [R, 3, R*b] (tiny)
-  5. merge: lowest key, then lowest GLOBAL index == np.argmin over the whole gallery
+  4. ONE all-gather of the packed per-rank results                   [R][{key, dist, idx}[R*b]] (tiny)
+  5. merge: lowest key (= the reference distance), then lowest GLOBAL index == np.argmin over the whole gallery
 
 There is no other collective on the data path.  The local compute (steps 1, 3, 5) is the
 HIP library; tests on CPU inject stand-ins for it to exercise steps 2 and 4.
@@ -22,6 +22,23 @@ def shard_bounds(n_rows, world_size, rank):
     base, extra = divmod(int(n_rows), int(world_size))
     lo = rank * base + min(rank, extra)
     return lo, lo + base + (1 if rank < extra else 0)
+
+
+class _StepBuffers:
+    """Device buffers of one (B, d) step shape, allocated once: the gathered probes, this rank's packed
+    partial result and the gathered partial results, the merged output."""
+
+    def __init__(self, world, b, d, dev):
+        B = world * b
+        self.probes = torch.empty((B, d), dtype=torch.float32, device=dev)
+        # one rank's record = { float key[B]; float dist[B]; int64 idx[B]; } (include/dif.h: dif_match_merge_packed)
+        self.packed = torch.empty((world, 4 * B), dtype=torch.float32, device=dev)
+        self.out_idx = torch.empty((B,), dtype=torch.int64, device=dev)
+        self.out_dist = torch.empty((B,), dtype=torch.float32, device=dev)
+
+    def record(self, rank, B):
+        rec = self.packed[rank]
+        return rec[0:B], rec[B:2 * B], rec[2 * B:4 * B].view(torch.int64)
 
 
 def _hip_match(gallery, probes, metric):
@@ -45,8 +62,9 @@ class ShardedGallery:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self._match = match_fn or _hip_match
-        self._merge = merge_fn or _hip_merge
+        self._match = match_fn
+        self._merge = merge_fn
+        self._bufs = {}
         if gallery is not None:
             self.gallery = gallery
         elif match_fn is None:
@@ -55,27 +73,51 @@ class ShardedGallery:
         else:
             self.gallery = (shard_rows, index_base)     # stand-in compute gets the raw shard
 
-    def all_gather_embeddings(self, local):
+    def all_gather_embeddings(self, local, out=None):
         """Step 2.  `local` is [b, d] on every rank (same b); returns [R*b, d]."""
         if self.world == 1:
             return local
-        out = torch.empty((self.world * local.shape[0], local.shape[1]), dtype=local.dtype, device=local.device)
+        if out is None:
+            out = torch.empty((self.world * local.shape[0], local.shape[1]), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
         return out
 
     def match(self, local_embeddings, distance_metric=1):
-        """Steps 2-5: returns (idx[R*b] int64 global, dist[R*b] float32), identical on every rank."""
+        """Steps 2-5: returns (idx[R*b] int64 global, dist[R*b] float32), identical on every rank.  On the HIP
+        path nothing is allocated per step: the match writes its (key, dist, idx) straight into this rank's
+        record of one packed buffer, ONE all-gather moves the records, dif_match_merge_packed reduces them.
+        (The returned tensors are reused by the next call of the same shape.)"""
+        if self._match is not None:
+            return self._match_injected(local_embeddings, distance_metric)
+        from . import _native as N
+        b, d = local_embeddings.shape
+        key = (b, d, local_embeddings.device)
+        buf = self._bufs.get(key)
+        if buf is None:
+            buf = self._bufs[key] = _StepBuffers(self.world, b, d, local_embeddings.device)
+        B = self.world * b
+        probes = self.all_gather_embeddings(local_embeddings, buf.probes)
+        k, dd, ix = buf.record(self.rank, B)
+        if self.world == 1:
+            self.gallery.match_into(probes, distance_metric, buf.out_idx, buf.out_dist)
+            return buf.out_idx, buf.out_dist
+        self.gallery.match_into(probes, distance_metric, ix, dd, k)
+        dist.all_gather_into_tensor(buf.packed.view(-1), buf.packed[self.rank], group=self.group)
+        N.check(N.lib.dif_match_merge_packed(N.ptr(buf.packed), self.world, B, N.ptr(buf.out_idx), N.ptr(buf.out_dist),
+                                             N.stream_ptr()))
+        return buf.out_idx, buf.out_dist
+
+    def _match_injected(self, local_embeddings, distance_metric):
+        """The same exchange with stand-in compute (CPU tests over gloo: the HIP kernels need a GPU)."""
         probes = self.all_gather_embeddings(local_embeddings)
         key, idx, d = self._match(self.gallery, probes, distance_metric)
         if self.world == 1:
             return idx, d
         B = probes.shape[0]
-        # (key, dist) travel as one float32 tensor, idx as int64: two all-gathers of a few KiB each
-        kd = torch.cat([key.to(torch.float32), d.to(torch.float32)])               # [2B]
-        kd_all = torch.empty((self.world * 2 * B,), dtype=kd.dtype, device=kd.device)
-        ix_all = torch.empty((self.world * B,), dtype=torch.int64, device=idx.device)
-        dist.all_gather_into_tensor(kd_all, kd.contiguous(), group=self.group)
-        dist.all_gather_into_tensor(ix_all, idx.contiguous(), group=self.group)
-        kd_all = kd_all.view(self.world, 2, B)
-        ix_all = ix_all.view(self.world, B)
-        return self._merge(kd_all[:, 0].contiguous(), ix_all, kd_all[:, 1].contiguous())
+        rec = torch.cat([key.to(torch.float32), d.to(torch.float32), idx.to(torch.int64).view(torch.float32)])   # [4B]
+        allrec = torch.empty((self.world * 4 * B,), dtype=torch.float32, device=rec.device)
+        dist.all_gather_into_tensor(allrec, rec.contiguous(), group=self.group)
+        allrec = allrec.view(self.world, 4 * B)
+        keys, dists = allrec[:, 0:B].contiguous(), allrec[:, B:2 * B].contiguous()
+        ix = allrec[:, 2 * B:4 * B].contiguous().view(torch.int64)
+        return (self._merge or _hip_merge)(keys, ix, dists)

@@ -30,6 +30,8 @@ extern "C" {
 /* distance metrics: evaluation/utility.py:52-66 */
 #define DIF_METRIC_SQL2 0   /* sum((a-b)^2, axis=1)                     utility.py:53-56 */
 #define DIF_METRIC_COSINE 1 /* arccos(a.b / (|a||b|)) / pi              utility.py:57-62 */
+#define DIF_METRIC_SIMILARITY 2 /* dif_pairwise only: the cosine similarity a.b / (|a||b|) itself, i.e.
+                                 * utility.py:58-60 before the arccos (common/losses.py:39-40 precedent) */
 
 /* input layouts / dtypes accepted by dif_net_embed */
 #define DIF_LAYOUT_NHWC 0 /* the reference's layout (networks/inceptionv3.py:94,98) */
@@ -106,15 +108,23 @@ int dif_gallery_destroy(dif_gallery* g);
  * per-row norms; index_base = global index of row 0 (gallery row-sharded over ranks) */
 int dif_gallery_set(dif_gallery* g, const float* rows_dev, int64_t n, int64_t index_base, void* stream);
 int64_t dif_gallery_size(const dif_gallery* g);
-/* top-1 search of n probes [n][d]: idx_out_dev[n] (int64 global index, first minimum),
- * dist_out_dev[n] (float32 distance in the reference's formula), key_out_dev[n]
- * (optional, may be NULL: monotone search key, comparable across gallery shards). */
+/* top-1 search of n probes [n][d]: idx_out_dev[n] = np.argmin over the reference's float32 distances
+ * (int64 global index; first minimum; a row whose reference distance is NaN -- similarity rounded
+ * above 1 -- ranks first, as in np.argmin), dist_out_dev[n] = that row's distance (similarity clamped
+ * to [-1, 1], so 0 where the reference has NaN), key_out_dev[n] (optional, may be NULL) = the ranking
+ * key: the reference distance itself, -inf for NaN; comparable across gallery shards. */
 int dif_match(dif_gallery* g, const float* probes_dev, int n, int metric, int64_t* idx_out_dev,
               float* dist_out_dev, float* key_out_dev, void* stream);
 /* merge R per-shard results laid out [R][n] (after an all-gather): lowest key, then
  * lowest global index -- equals np.argmin over the concatenated gallery */
 int dif_match_merge(const float* keys_dev, const int64_t* idx_dev, const float* dist_dev, int R, int n,
                     int64_t* idx_out_dev, float* dist_out_dev, void* stream);
+/* the same merge over ONE all-gathered buffer of R per-rank records, each n*16 bytes:
+ * { float key[n]; float dist[n]; int64 idx[n]; } -- dif_match can write its three outputs straight
+ * into a rank's record (key_out = rec, dist_out = rec + n floats, idx_out = rec + 2n floats), so the
+ * N>1 step needs one collective for the partial results */
+int dif_match_merge_packed(const void* packed_dev, int R, int n, int64_t* idx_out_dev, float* dist_out_dev,
+                           void* stream);
 
 /* ------------------------------------------------------------------ embedding network
  * Stands behind the Keras model object of the reference:

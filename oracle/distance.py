@@ -128,3 +128,43 @@ def match_blas(probes, gallery, distance_metric=1):
         idx = np.argmin(d, axis=1)
         return idx.astype(np.int64), d[np.arange(p.shape[0]), idx].astype(np.float32)
     raise RuntimeError('Undefined distance metric %d' % distance_metric)
+
+
+# --------------------------------------------------------------------------- summation order
+def np_pairwise_sum(a):
+    """What ``np.sum(x, axis=1)`` / ``np.add.reduce`` does to ONE contiguous float32 row, spelled out
+    (NumPy 2.2.6, numpy/_core/src/umath/loops_utils.h.src: @TYPE@_pairwise_sum): n < 8 a plain loop;
+    n <= 128 eight interleaved accumulators, combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the
+    n % 8 leftovers in order; larger n split at n/2 rounded down to a multiple of 8, recursively.
+    The reference's distances (evaluation/utility.py:54-62) are these sums of float32 products, so this
+    order -- not the mathematical sum -- is what decides its arg-min on near-ties.  csrc/match.hip
+    (np_sum) evaluates the same tree on the device; tests/test_oracle_golden.py pins this restatement
+    against np.sum itself bit for bit."""
+    f32 = np.float32
+    a = np.asarray(a, dtype=np.float32)
+    n = a.shape[0]
+    if n < 8:
+        res = f32(0.0)
+        for x in a:
+            res = f32(res + x)
+        return res
+    if n <= 128:
+        r = [a[j] for j in range(8)]
+        body = n - (n % 8)
+        for i in range(8, body, 8):
+            for j in range(8):
+                r[j] = f32(r[j] + a[i + j])
+        res = f32(f32(f32(r[0] + r[1]) + f32(r[2] + r[3])) + f32(f32(r[4] + r[5]) + f32(r[6] + r[7])))
+        for i in range(body, n):
+            res = f32(res + a[i])
+        return res
+    n2 = n // 2
+    n2 -= n2 % 8
+    return f32(np_pairwise_sum(a[:n2]) + np_pairwise_sum(a[n2:]))
+
+
+def similarity(embeddings1, embeddings2):
+    """The cosine similarity inside ``distance(.., 1)`` (evaluation/utility.py:58-60), float32."""
+    num = (embeddings1 * embeddings2).sum(axis=1)
+    den = np.linalg.norm(embeddings1, axis=1) * np.linalg.norm(embeddings2, axis=1)
+    return num / den

@@ -77,7 +77,63 @@ def main():
             k = 'm%d_s%d' % (metric, int(sub))
             rec['tpr_' + k], rec['fpr_' + k], rec['acc_' + k], rec['f1_' + k] = tpr, fpr, acc, f1
     np.savez(os.path.join(OUT, 'roc.npz'), **rec)
+
+    # 5. near-ties: the reference's arg-min where float32 distances collide -----------
+    probes, gallery = gi.match_near_tie_inputs()
+    rec = {'sha': gi.digest(probes, gallery)}
+    with np.errstate(invalid='ignore'):
+        for metric in (0, 1):
+            idx, dmin, nties, nnan = [], [], [], []
+            for q in probes:
+                d = ref_utility.distance(q[None, :], gallery, metric)
+                i = int(np.argmin(d))
+                idx.append(i)
+                dmin.append(d[i])
+                nties.append(int(np.count_nonzero(d == d[i])))
+                nnan.append(int(np.count_nonzero(np.isnan(d))))
+            rec['idx%d' % metric] = np.array(idx, dtype=np.int64)
+            rec['dmin%d' % metric] = np.array(dmin, dtype=np.float32)
+            rec['nties%d' % metric] = np.array(nties, dtype=np.int32)     # rows sharing the minimal float32 distance
+            rec['nnan%d' % metric] = np.array(nnan, dtype=np.int32)       # rows whose reference distance is NaN (s > 1)
+    np.savez(os.path.join(OUT, 'match_near_ties.npz'), **rec)
+
+    # 6. structure the reference holds as DATA (no TensorFlow needed to read it) ------
+    write_structure(os.path.join(OUT, 'structure.json'))
     print('wrote', sorted(os.listdir(OUT)))
+
+
+def write_structure(path):
+    """NN4.small2's layer-name list and weight-shape table (networks/inceptionv3.py: WEIGHTS, conv_shape),
+    read with `ast` from the module's source without importing it (it needs Keras), and the YOLOv3-face
+    Darknet cfg (detector/yolo_cfg/yolov3-face.cfg) parsed into its section list.  Values only."""
+    import ast
+    import json
+    src = open('/root/reference/deep_insight_face/networks/inceptionv3.py').read()
+    table = {}
+    for node in ast.parse(src).body:
+        if isinstance(node, ast.Assign) and len(node.targets) == 1 and isinstance(node.targets[0], ast.Name) \
+                and node.targets[0].id in ('WEIGHTS', 'conv_shape'):
+            table[node.targets[0].id] = ast.literal_eval(node.value)
+    assert len(table['conv_shape']) == 37 and 'dense_layer' in table['WEIGHTS']
+    sections = []
+    for raw in open('/root/reference/deep_insight_face/detector/yolo_cfg/yolov3-face.cfg'):
+        line = raw.split('#', 1)[0].strip()
+        if not line:
+            continue
+        if line.startswith('['):
+            sections.append({'type': line.strip('[]')})
+        else:
+            k, v = [t.strip() for t in line.split('=', 1)]
+            sections[-1][k] = v
+    keep = {'type', 'batch_normalize', 'filters', 'size', 'stride', 'pad', 'activation', 'from', 'layers', 'mask',
+            'anchors', 'classes', 'num', 'width', 'height', 'channels'}
+    sections = [{k: v for k, v in s.items() if k in keep} for s in sections]
+    def _read(name):
+        return open('/root/reference/deep_insight_face/detector/yolo_cfg/' + name).read().split()
+    with open(path, 'w') as fh:
+        json.dump({'nn4_weights': table['WEIGHTS'], 'nn4_conv_shape': table['conv_shape'],
+                   'yolov3_face_cfg': sections, 'yolo_anchors_txt': ' '.join(_read('yolo_anchors.txt')),
+                   'face_classes_txt': _read('face_classes.txt')}, fh, indent=0, sort_keys=True)
 
 
 if __name__ == '__main__':

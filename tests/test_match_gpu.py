@@ -75,7 +75,7 @@ def test_match_vs_golden(cuda, golden_dir, name, maker):
         assert np.array_equal(idx, g['idx%d' % m]), (m, idx, g['idx%d' % m])
         want = g['full%d' % m][np.arange(len(idx)), idx]
         if m == 0:
-            np.testing.assert_allclose(dist, want, rtol=2e-6, atol=ATOL)
+            assert np.array_equal(dist, want)               # bit-identical: same float32 operations, same order
         else:
             sim = np.cos(want.astype(np.float64) * np.pi)
             ok = _cos_ok(sim)
@@ -224,3 +224,116 @@ def test_match_million_row_gallery(cuda):
     i2, _ = g2.match(probes, 1)
     assert torch.equal(i2, pick)
     g2.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# Near-ties: the search key only filters; the winner is chosen on the reference's own float32
+# arithmetic (csrc/match.hip stages 2 and 3)
+def test_reference_arithmetic_bit_exact(cuda, golden_dir):
+    """dif_pairwise evaluates utility.py:54-62 in NumPy's summation order: metric 0 is bit-identical to
+    the reference's output, and so is the cosine similarity inside metric 1 (DIF_METRIC_SIMILARITY); the
+    distance of metric 1 differs from the reference's only through arccos (NumPy: SVML, <= 2 ulp)."""
+    from deep_insight_face import _native as N
+    from deep_insight_face.evaluation import utility
+    g = np.load(os.path.join(golden_dir, 'distance_pairs.npz'))
+    e1, e2 = gi.pair_inputs()
+    d0 = utility.distance(e1, e2, 0)
+    assert np.array_equal(d0.view(np.uint32), g['d0'].view(np.uint32))
+    rng = np.random.default_rng(5)
+    for d in (512, 128, 96, 77, 8, 7, 1000, 129):
+        a = (rng.standard_normal((33, d)) * rng.uniform(0.1, 30, (33, 1))).astype(np.float32)
+        b = (a + 0.3 * rng.standard_normal((33, d))).astype(np.float32)
+        b[0] = a[0]
+        ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+        for metric, want in ((0, od.distance(a, b, 0)), (2, od.similarity(a, b))):
+            out = torch.empty(33, dtype=torch.float32, device='cuda')
+            N.check(N.lib.dif_pairwise(N.ptr(ta), 33, N.ptr(tb), 33, d, metric, N.ptr(out), N.stream_ptr()))
+            assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32)), (d, metric)
+        with np.errstate(invalid='ignore'):
+            want1 = od.distance(a, b, 1)
+        got1 = utility.distance(a, b, 1)
+        ok = ~np.isnan(want1)
+        assert np.abs(got1[ok].view(np.int32).astype(np.int64) - want1[ok].view(np.int32)).max() <= 4   # ulps
+        assert np.all(got1[~ok] == 0.0)                    # reference NaN (s > 1) <-> clamped to distance 0
+
+
+@pytest.mark.parametrize('metric', [0, 1])
+def test_match_near_ties_vs_golden(cuda, golden_dir, metric):
+    """Gallery rows 1 ulp / 1e-7 / 1e-4 apart from each other and from the probes, exact duplicates,
+    unnormalised rows with large |g|^2: the HIP arg-min equals the reference's on every probe, including
+    the probes whose reference distance is NaN (np.argmin: first NaN)."""
+    from deep_insight_face import oneshot
+    g = np.load(os.path.join(golden_dir, 'match_near_ties.npz'))
+    probes, gallery = gi.match_near_tie_inputs()
+    assert np.array_equal(g['sha'], gi.digest(probes, gallery))
+    gal = oneshot.Gallery(gallery)
+    idx, dist, key = gal.match(probes, metric, return_key=True)
+    assert np.array_equal(idx, g['idx%d' % metric]), np.nonzero(idx != g['idx%d' % metric])
+    want = g['dmin%d' % metric]
+    if metric == 0:
+        assert np.array_equal(dist.view(np.uint32), want.view(np.uint32))
+        assert np.array_equal(key, dist)
+    else:
+        nan = np.isnan(want)
+        assert nan.sum() >= 5
+        assert np.all(dist[nan] == 0.0) and np.all(np.isneginf(key[nan]))
+        assert np.abs(dist[~nan].view(np.int32).astype(np.int64) - want[~nan].view(np.int32)).max() <= 4
+    # one probe at a time and in ragged groups (other tiles, other block counts): same winners
+    for lo, hi in ((0, 1), (1, 34), (34, 48)):
+        i2, _ = gal.match(probes[lo:hi], metric)
+        assert np.array_equal(i2, g['idx%d' % metric][lo:hi])
+    gal.close()
+
+
+@pytest.mark.parametrize('metric', [0, 1])
+def test_match_near_ties_sharded(cuda, golden_dir, metric):
+    """The same fixture row-sharded 3 and 7 ways + the packed merge (parallel.py's N > 1 record layout)."""
+    from deep_insight_face import oneshot, _native as N
+    from deep_insight_face.parallel import shard_bounds
+    g = np.load(os.path.join(golden_dir, 'match_near_ties.npz'))
+    probes, gallery = gi.match_near_tie_inputs()
+    B = probes.shape[0]
+    p_t = torch.from_numpy(probes).cuda()
+    for R in (3, 7):
+        packed = torch.empty((R, 4 * B), dtype=torch.float32, device='cuda')
+        for r in range(R):
+            lo, hi = shard_bounds(gallery.shape[0], R, r)
+            sh = oneshot.Gallery(gallery[lo:hi], index_base=lo)
+            rec = packed[r]
+            sh.match_into(p_t, metric, rec[2 * B:].view(torch.int64), rec[B:2 * B], rec[:B])
+            torch.cuda.synchronize()
+            sh.close()
+        oi = torch.empty(B, dtype=torch.int64, device='cuda')
+        odist = torch.empty(B, dtype=torch.float32, device='cuda')
+        N.check(N.lib.dif_match_merge_packed(N.ptr(packed), R, B, N.ptr(oi), N.ptr(odist), N.stream_ptr()))
+        assert np.array_equal(oi.cpu().numpy(), g['idx%d' % metric]), R
+
+
+def test_match_exact_search_on_overflow(cuda):
+    """More near-minimal rows in one block than a candidate list holds (KCAND = 8): the probe is re-searched
+    exactly over the whole gallery.  300 copies of the best row, the genuinely lowest index hidden among
+    later ones, plus a row one ulp better at a high index for metric 0."""
+    from deep_insight_face import oneshot
+    G = 3000
+    gal_np = gi.gallery(G, seed=55)
+    rng = np.random.default_rng(56)
+    probes, _ = gi.probes_from(gal_np, 6, seed=57)
+    for b in range(6):
+        base = gi._unit((probes[b] + 0.01 * rng.standard_normal(512))[None].astype(np.float32))[0]
+        rows = np.sort(rng.choice(G, 300, replace=False))
+        gal_np[rows] = base
+    gal = oneshot.Gallery(gal_np)
+    for m in (0, 1):
+        with np.errstate(invalid='ignore'):
+            oi, odist, _ = od.match(probes, gal_np, m)
+        idx, dist = gal.match(probes, m)
+        assert np.array_equal(idx, oi)
+        if m == 0:
+            assert np.array_equal(dist, odist)
+    # a 4-probe batch next to them that does NOT overflow is unaffected
+    clean, pick = gi.probes_from(gi.gallery(G, seed=55), 4, seed=58)
+    i2, _ = gal.match(np.concatenate([probes[:2], clean]), 1)
+    with np.errstate(invalid='ignore'):
+        oi2, _, _ = od.match(np.concatenate([probes[:2], clean]), gal_np, 1)
+    assert np.array_equal(i2, oi2)
+    gal.close()

@@ -23,17 +23,6 @@ def cosine_gap(a, b):
     return 1.0 - (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
 
 
-def test_nn4_shapes_follow_the_reference_table():
-    # the reference's own conv_shape table (inceptionv3.py:365-403) as [cout, cin, kh, kw]
-    spec = dict(nets.nn4_spec(128))
-    assert spec['conv1/kernel'] == (7, 7, 3, 64)
-    assert spec['inception_3a_5x5_conv2/kernel'] == (5, 5, 16, 32)
-    assert spec['inception_4e_3x3_conv2/kernel'] == (3, 3, 160, 256)
-    assert spec['inception_5b_1x1_conv/kernel'] == (1, 1, 736, 256)
-    assert spec['dense_layer/kernel'] == (736, 128)
-    assert len([k for k in spec if k.endswith('/kernel')]) == 38     # 37 convolutions + dense
-
-
 def test_nn4_library_table_matches_oracle():
     from deep_insight_face.networks.inceptionv3 import InceptionNetwork
     net = InceptionNetwork((96, 96, 3), 128)
@@ -67,3 +56,32 @@ def test_nn4_gpu_vs_oracle(cuda, n):
     assert cosine_gap(got, want).max() < 1e-5
     np.testing.assert_allclose(got, want, atol=2e-4)
     assert np.array_equal(net(x), got)          # __call__ passthrough, deterministic
+
+
+def test_openface_csv_weights_round_trip(tmp_path):
+    """The reference's CSV weight directory (inceptionv3.py:28-60): written here the way OpenFace ships it
+    ([cout, cin, kh, kw]-ordered flat conv kernels, [128, 736] dense), read by the mirror of the reference's
+    loader, compared with the source parameters; then through InceptionNetwork._load_weights."""
+    import os
+    from deep_insight_face.networks import inceptionv3 as inc
+    p = synth()
+    d = str(tmp_path)
+    for name, a in p.items():
+        layer, leaf = name.rsplit('/', 1)
+        if leaf == 'kernel' and a.ndim == 4:
+            np.savetxt(os.path.join(d, layer + '_w.csv'), np.transpose(a, (3, 2, 0, 1)).reshape(1, -1), delimiter=',', fmt='%.9g')
+        elif leaf == 'kernel':
+            np.savetxt(os.path.join(d, 'dense_w.csv'), a.T.reshape(1, -1), delimiter=',', fmt='%.9g')
+        else:
+            suffix = {'bias': '_b', 'gamma': '_w', 'beta': '_b', 'moving_mean': '_m', 'moving_variance': '_v'}[leaf]
+            stem = 'dense' if layer == 'dense_layer' else layer
+            np.savetxt(os.path.join(d, stem + suffix + '.csv'), a.reshape(1, -1), delimiter=',', fmt='%.9g')
+    w = inc.load_weights(d)
+    assert len(w) == 37 + 37 + 1
+    assert w['conv1'][0].shape == (7, 7, 3, 64) and np.array_equal(w['conv1'][0], p['conv1/kernel'])
+    assert np.array_equal(w['dense_layer'][0], p['dense_layer/kernel'])
+    assert np.array_equal(w['inception_4e_5x5_bn2'][3], p['inception_4e_5x5_bn2/moving_variance'])
+    net = inc.InceptionNetwork((96, 96, 3), 128)
+    net._load_weights(d)
+    got = net.get_weights()
+    assert set(got) == set(p) and all(np.array_equal(got[k], p[k]) for k in p)

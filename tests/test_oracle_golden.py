@@ -107,3 +107,39 @@ def test_roc_pieces(golden_dir):
             assert np.array_equal(fpr, g['fpr_' + k])
             assert np.array_equal(accs, g['acc_' + k])
             assert np.array_equal(f1, g['f1_' + k])
+
+
+def test_near_tie_fixture(golden_dir):
+    """The near-tie fixture: inputs reproduce, the oracle's arg-min equals the reference's, and the
+    fixture really holds what it is for -- probes with several rows at the minimal float32 distance,
+    and probes whose reference distance is NaN (similarity rounded above 1: np.argmin returns the
+    first such row)."""
+    g = load(golden_dir, 'match_near_ties.npz')
+    probes, gallery = gi.match_near_tie_inputs()
+    assert np.array_equal(g['sha'], gi.digest(probes, gallery))
+    with np.errstate(invalid='ignore'):
+        for m in (0, 1):
+            idx, best, _ = od.match(probes, gallery, m)
+            assert np.array_equal(idx, g['idx%d' % m])
+            assert np.array_equal(best, g['dmin%d' % m], equal_nan=True)
+    assert (g['nties0'] > 1).sum() >= 10 and (g['nties1'] > 1).sum() >= 10
+    assert (g['nnan1'] > 0).sum() >= 5 and g['nnan0'].sum() == 0
+
+
+def test_numpy_summation_order_restated():
+    """oracle.distance.np_pairwise_sum == np.sum(axis=1), bit for bit, for the row lengths the product
+    meets (512, 128) and the awkward ones (tails, < 8, splits that are not powers of two)."""
+    rng = np.random.default_rng(0)
+    for d in (512, 128, 100, 7, 1000, 513, 2048, 64, 96, 129, 255, 8, 9, 1):
+        a = rng.standard_normal((6, d)).astype(np.float32)
+        want = np.sum(a, axis=1)
+        got = np.array([od.np_pairwise_sum(r) for r in a])
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), d
+    # the three sums of the cosine distance, as the reference forms them (products rounded first)
+    q = rng.standard_normal((1, 512)).astype(np.float32)
+    gal = rng.standard_normal((20, 512)).astype(np.float32)
+    dot = np.sum(np.multiply(q, gal), axis=1)
+    nrm = np.linalg.norm(gal, axis=1)
+    for r in range(20):
+        assert od.np_pairwise_sum(q[0] * gal[r]) == dot[r]
+        assert np.sqrt(od.np_pairwise_sum(gal[r] * gal[r])) == nrm[r]

@@ -75,3 +75,43 @@ def test_two_ranks_one_gpu(cuda, tmp_path):
             else:
                 np.testing.assert_allclose(np.cos(z['d%d' % m].astype(np.float64) * np.pi),
                                            np.cos(want_d.astype(np.float64) * np.pi), atol=1e-5)
+
+
+def _step_worker(rank, world, port, b, G, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        dist.all_gather_into_tensor = _CpuCollectives()
+        from deep_insight_face.networks.triplet import DifEmbedder
+        from deep_insight_face.parallel import ShardedGallery, shard_bounds
+        model = DifEmbedder('resnet', 'v2', 512, (112, 112, 3), max_batch=world * b).init_synthetic(2024)
+        model.set_input_transform(scale=1 / 255.)
+        rng = np.random.default_rng(77)
+        enrol = rng.integers(0, 256, (world * b, 112, 112, 3), dtype=np.uint8)
+        noisy = np.clip(enrol.astype(np.int64) + rng.integers(-5, 6, enrol.shape), 0, 255).astype(np.uint8)
+        gal = gi.gallery(G, seed=3)
+        pos = np.random.default_rng(78).choice(G, world * b, replace=False)
+        gal_t = torch.from_numpy(gal).cuda()
+        gal_t[torch.from_numpy(pos).cuda()] = model.embed(torch.from_numpy(enrol).cuda())
+        lo, hi = shard_bounds(G, world, rank)
+        sg = ShardedGallery(gal_t[lo:hi], lo)
+        mine = torch.from_numpy(noisy[rank * b:(rank + 1) * b]).cuda()
+        for _ in range(2):                                   # second pass reuses the preallocated step buffers
+            idx, d = sg.match(model.embed(mine), 1)
+        np.savez(os.path.join(out_dir, 's%d.npz' % rank), idx=idx.cpu().numpy(), d=d.cpu().numpy(), pos=pos)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_whole_step(cuda, tmp_path):
+    """The whole N > 1 step on two ranks: per-rank embed of its half of the batch -> all-gather of the
+    embeddings -> match against the rank's gallery shard -> ONE all-gather of the packed partial records
+    -> dif_match_merge_packed.  Every rank must name the planted enrolment of every probe of both ranks."""
+    world, b, G = 2, 6, 2001
+    mp.spawn(_step_worker, args=(world, _free_port(), b, G, str(tmp_path)), nprocs=world, join=True)
+    z0 = np.load(os.path.join(str(tmp_path), 's0.npz'))
+    z1 = np.load(os.path.join(str(tmp_path), 's1.npz'))
+    assert np.array_equal(z0['idx'], z0['pos']) and np.array_equal(z1['idx'], z0['pos'])
+    assert np.array_equal(z0['d'], z1['d']) and float(z0['d'].max()) < 0.2

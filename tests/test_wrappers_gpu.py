@@ -160,3 +160,21 @@ def test_siamese_module(cuda):
         siamese.bottleneck_network('inception')
     base.close()
     v2.close()
+
+
+def test_prediction_wrappers_keep_the_callers_transform(cuda):
+    """_embedding must put back the transform the caller had set on the shared model (bench.py and
+    FramePipeline run uint8 crops with scale 1/255), not reset it to the identity."""
+    from deep_insight_face.networks.triplet import DifEmbedder
+    from deep_insight_face.predictions import SiamesePrediction, TripletPrediction
+    model = DifEmbedder('resnet', 'v2', 128, (112, 112, 3), max_batch=4).init_synthetic(3)
+    model.set_input_transform(scale=1 / 255.)
+    u8 = crops_u8(2, seed=9)
+    before = model.predict_on_batch(u8)
+    TripletPrediction(model, img_size=(112, 112))._embedding(u8[0])
+    assert model._transform[0] == pytest.approx(1 / 255.)
+    assert np.array_equal(model.predict_on_batch(u8), before)
+    SiamesePrediction(model, img_size=(112, 112))._embedding(u8[1])
+    assert model._transform == (pytest.approx(1 / 255.), (0.0, 0.0, 0.0), False, False)
+    assert np.array_equal(model.predict_on_batch(u8), before)
+    model.close()
