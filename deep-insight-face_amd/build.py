@@ -36,6 +36,16 @@ def _digest(path):
     return h.hexdigest()
 
 
+def _file_flags(path):
+    """A source may pin compiler flags of its own on a `// hipcc-flags: ...` line (match.hip turns FMA
+    contraction off: its re-rank restates the reference's float32 arithmetic operation by operation)."""
+    with open(path) as fh:
+        for line in fh:
+            if line.startswith('// hipcc-flags:'):
+                return line.split(':', 1)[1].split()
+    return []
+
+
 def _compile(src):
     path = os.path.join(CSRC, src)
     obj = os.path.join(OBJ, src + '.o')
@@ -43,7 +53,7 @@ def _compile(src):
     dig = _digest(path)
     if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig and '--force' not in sys.argv:
         return obj, False
-    cmd = [HIPCC] + FLAGS + ['-c', path, '-o', obj]
+    cmd = [HIPCC] + FLAGS + _file_flags(path) + ['-c', path, '-o', obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError('hipcc failed for %s:\n%s\n%s' % (src, r.stdout, r.stderr))

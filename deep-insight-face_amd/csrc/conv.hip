@@ -880,7 +880,8 @@ static int allow_dynamic_lds(K kern, int bytes) {
 }
 
 int conv_max_blocks() { return 4 * num_cus(); }
-size_t conv_slab_floats() { return 2 * 64 * 64; }   // per block: the published partial + the fallback stash (64x64 tile)
+size_t conv_slab_floats() { return 128 * 128; }   // per resident slot: published partial + fallback stash, either tile
+                                                   // (1024 x 2 x 64x64 or 512 x 2 x 128x128 floats in all)
 
 template <class T, bool PRE, bool DMA, int AM>
 static int launch_conv_pre(const ConvArgs& a, hipStream_t st);
@@ -934,7 +935,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
   // other tile shapes are experiment knobs and keep the general gather)
   static const bool use_pw = !(getenv("DIF_NO_PW") && atoi(getenv("DIF_NO_PW")));
   constexpr bool kDefaultTile = (T::BM == 64 && T::BN == 64);
-  const bool pw = kDefaultTile && use_pw && a.KH == 1 && a.KW == 1 && a.pad_t == 0 && a.pad_l == 0 && a.Cin % BK == 0;
+  const bool pw = use_pw && a.KH == 1 && a.KW == 1 && a.pad_t == 0 && a.pad_l == 0 && a.Cin % BK == 0;
   // (a compile-time specialisation of the 3x3 gather, KMODE 2, was measured 5 % SLOWER than the
   // run-time-selected path on IResNet-100 -- hipcc schedules the loop differently -- so the
   // multi-tap layers stay on the general loader)
@@ -950,9 +951,9 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
       if (pw) return launch_conv_pipe<T, false, 1, 4>(a, st);
       if (!a.pre_scale) return launch_conv_pipe<T, false, 0, 1>(a, st);
     }
-    if (pw && a.pre_scale) return launch_conv_pre<T, true, false, 1>(a, st);
-    if (pw) return launch_conv_pre<T, false, false, 1>(a, st);
   }
+  if (pw && a.pre_scale) return launch_conv_pre<T, true, false, 1>(a, st);
+  if (pw) return launch_conv_pre<T, false, false, 1>(a, st);
   if (a.pre_scale) return launch_conv_pre<T, true, false, 0>(a, st);
   if (use_dma) return launch_conv_pre<T, false, true, 0>(a, st);
   return launch_conv_pre<T, false, false, 0>(a, st);
@@ -967,7 +968,7 @@ static int launch_conv_pre(const ConvArgs& a, hipStream_t st) {
   const int64_t I = tiles * KS;
   if (I >= 0x7fffffffLL) return set_error("conv: iteration space too large");
   // Resident blocks for this tile shape (LDS-limited: 2 per CU, 4 for the 64x64 tile).
-  int64_t slots = (T::LDS_BYTES * 4 <= 160 * 1024 ? 4 : 2) * (int64_t)num_cus();
+  int64_t slots = T::BLOCKS_PER_CU * (int64_t)num_cus();
   if (slots > a.sk_max_blocks) slots = a.sk_max_blocks;
   // Many tiles, or a short K loop (< 32 steps: a split tile's slab hand-off would cost more
   // than the imbalance it removes -- measured): one whole tile per block, the hardware
@@ -1001,6 +1002,14 @@ static int launch_conv_pre(const ConvArgs& a, hipStream_t st) {
   return 0;
 }
 
+static bool conv_big_tile(const ConvArgs& a) {
+  static const int mode = getenv("DIF_CONV_TILE") ? atoi(getenv("DIF_CONV_TILE")) : 0;   // 0 never, 1 by rule, 2 wherever legal
+  if (mode == 0 || a.Cin % 4 != 0 || a.Cout % 4 != 0) return false;
+  if (mode == 2) return a.Cout >= 64;
+  static const int min_ks = getenv("DIF_BIG_MIN_KS") ? atoi(getenv("DIF_BIG_MIN_KS")) : 18;
+  return a.Cout % 128 == 0 && a.Kpad / BK >= min_ks;
+}
+
 // One tile shape ships: 64x64 (four blocks per CU).  Measured per layer over both networks in round 1
 // against 128x128 / 128x64 / 64x128: it wins or ties everywhere (four co-resident blocks keep the MFMA pipe
 // fed across each block's barriers, prologue and epilogue; the larger tiles spilled at the register budget
@@ -1025,6 +1034,10 @@ int conv_run(const ConvArgs& a, hipStream_t st) {
     if (span * a.H * a.W * a.Cin * 4 >= 0x7fffffffLL)
       return set_error("conv: a 256-pixel tile spans more than 2 GiB of input (%dx%dx%d)", a.H, a.W, a.Cin);
   }
+  // Two tile shapes ship (see the comment above): 64x64 / 4 waves, and 128x128 / 8 waves (each wave 64x32) for
+  // layers with a long K loop and at least 128 output channels: half the operand staging, barriers and
+  // address arithmetic per MFMA at the same four waves per SIMD.
+  if (conv_big_tile(a)) return launch_conv<Tile<2, 1, 2, 4>>(a, st);
   return launch_conv<Tile<1, 1>>(a, st);
 }
 

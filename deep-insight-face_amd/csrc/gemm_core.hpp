@@ -47,9 +47,13 @@ struct Tile {
   static constexpr int NB = BN / RP;
   static constexpr int LDS_FLOATS = 2 * (BM + BN) * LDS_STRIDE;
   static constexpr int LDS_BYTES = LDS_FLOATS * 4;
-  // blocks per CU the kernels are built for: LDS-limited (160 KiB); 4 blocks of 4 waves = 4 waves per SIMD,
-  // i.e. at most 128 VGPRs -- handed to __launch_bounds__ so the compiler holds that line
-  static constexpr int MIN_BLOCKS = LDS_BYTES * 4 <= 160 * 1024 ? 4 : 2;
+  // blocks per CU the kernels are built for: LDS-limited (160 KiB)
+  static constexpr int BLOCKS_PER_CU = LDS_BYTES * 4 <= 160 * 1024 ? 4 : 2;
+  // ... and the waves per SIMD that makes (4 blocks of 4 waves, or 2 blocks of 8 waves = 4 waves per SIMD,
+  // i.e. at most 128 VGPRs): the second argument of __launch_bounds__, which on HIP is waves per
+  // execution unit (MI355X_MICROARCH.md "Terms"), so the compiler holds that register line
+  static constexpr int WAVES_PER_EU = BLOCKS_PER_CU * WGM * WGN / 4;
+  static constexpr int MIN_BLOCKS = WAVES_PER_EU;
   static_assert(BM % RP == 0 && BN % RP == 0, "tile rows must be a multiple of the staging pass");
   __device__ static __forceinline__ int wave_row() { return (threadIdx.x >> 6) / WGN; }
   __device__ static __forceinline__ int wave_col() { return (threadIdx.x >> 6) % WGN; }

@@ -1,4 +1,7 @@
 // 1:N gallery match and the small distance kernels.
+// hipcc-flags: -ffp-contract=off
+// (no implicit a*b+c fusion anywhere in this file: stage 2 below restates the reference's float32
+// operations one by one; the search key uses explicit fmaf where a fused multiply-add is meant)
 //
 // Semantics (deep_insight_face/evaluation/utility.py:52-66 broadcast over gallery rows
 // + np.argmin, see SURVEY.md section 3 "1:N gallery search"):
