@@ -433,10 +433,12 @@ __device__ __forceinline__ int xcd_remap(int b, int P) {
 
 // AM (A-operand gather mode): 0 general, 1 pointwise (1x1, no padding, Cin % 32 == 0),
 // 2 multi-tap with Cin % 32 == 0 and channel-block-major K
-template <class T, bool PRE, bool DMA, int AM>
+// BF3: the split-bf16 mainloop (gemm_core.hpp: gemm_mainloop_bf3) on pre-split weights a.w3
+template <class T, bool PRE, bool DMA, int AM, bool BF3 = false>
 __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const ConvArgs a) {
   static_assert(!(PRE && DMA), "pre-activation needs register staging");
   static_assert(!(AM != 0 && DMA), "the specialised loaders are register-staged");
+  static_assert(!(BF3 && DMA), "the split-bf16 mainloop stages through registers");
   constexpr int WM = T::WM, WN = T::WN;
   constexpr int SLAB = T::BM * T::BN;    // floats per partial-accumulator slab
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -487,14 +489,24 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const 
     using ALoadReg = typename std::conditional<AM == 1, ConvPwLoader<T::NA, T::RP, PRE>,
                                                ConvALoader<T::NA, T::RP, PRE, AM == 2 ? 2 : 0>>::type;
     using ALoad = typename std::conditional<DMA, ConvADmaLoader<T::NA, T::RP>, ALoadReg>::type;
-    using BLoad = typename std::conditional<DMA, DmaRowLoader<T::NB, T::RP>, RowLoader<T::NB, T::RP>>::type;
+    using BLoadF32 = typename std::conditional<DMA, DmaRowLoader<T::NB, T::RP>, RowLoader<T::NB, T::RP>>::type;
+    using BLoad = typename std::conditional<BF3, Bf3WeightLoader<T>, BLoadF32>::type;
     ALoad al(a, m0);
-    BLoad bl(a.w + (int64_t)n0 * a.Kpad, (int64_t)a.Cout - n0, a.Kpad);
+    BLoad bl = [&] {
+      if constexpr (BF3)
+        return BLoad(static_cast<const char*>(a.w3) + (int64_t)n0 * KS * BF3_KSTEP_BYTES, (int64_t)a.Cout - n0, KS);
+      else
+        return BLoad(a.w + (int64_t)n0 * a.Kpad, (int64_t)a.Cout - n0, a.Kpad);
+    }();
     // this block computes the whole tile: fetch the shortcut tile behind the last K-step
     const bool whole = !DMA && kb == 0 && ke == KS;
     EpiRes<T> er;
     auto run = [&](int k0, int k1, bool prefetch_res) {
-      if constexpr (DMA)
+      if constexpr (BF3)
+        gemm_mainloop_bf3<T>(al, bl, k0, k1, reinterpret_cast<char*>(smem), acc, [&] {
+          if (prefetch_res && a.res) er.load(a, m0, n0);
+        });
+      else if constexpr (DMA)
         gemm_mainloop_dma<T>(al, bl, k0, k1, smem, acc);
       else
         gemm_mainloop2<T>(al, bl, k0, k1, smem, acc, [&] {
@@ -883,7 +895,7 @@ int conv_max_blocks() { return 4 * num_cus(); }
 size_t conv_slab_floats() { return 128 * 128; }   // per resident slot: published partial + fallback stash, either tile
                                                    // (1024 x 2 x 64x64 or 512 x 2 x 128x128 floats in all)
 
-template <class T, bool PRE, bool DMA, int AM>
+template <class T, bool PRE, bool DMA, int AM, bool BF3 = false>
 static int launch_conv_pre(const ConvArgs& a, hipStream_t st);
 
 // Short K loop, several whole tiles per resident block, plain output, unit-stride shortcut: the
@@ -959,16 +971,17 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
   return launch_conv_pre<T, false, false, 0>(a, st);
 }
 
-template <class T, bool PRE, bool DMA, int AM>
+template <class T, bool PRE, bool DMA, int AM, bool BF3>
 static int launch_conv_pre(const ConvArgs& a, hipStream_t st) {
-  auto kern = conv_igemm_kernel<T, PRE, DMA, AM>;
-  if (allow_dynamic_lds(kern, T::LDS_BYTES)) return -1;
+  auto kern = conv_igemm_kernel<T, PRE, DMA, AM, BF3>;
+  constexpr int lds_bytes = BF3 ? Bf3<T>::LDS_BYTES : T::LDS_BYTES;
+  if (allow_dynamic_lds(kern, lds_bytes)) return -1;
   const int64_t tiles = ((a.M + T::BM - 1) / T::BM) * (int64_t)((a.Cout + T::BN - 1) / T::BN);
   const int KS = a.Kpad / BK;
   const int64_t I = tiles * KS;
   if (I >= 0x7fffffffLL) return set_error("conv: iteration space too large");
   // Resident blocks for this tile shape (LDS-limited: 2 per CU, 4 for the 64x64 tile).
-  int64_t slots = T::BLOCKS_PER_CU * (int64_t)num_cus();
+  int64_t slots = (BF3 ? 2 : T::BLOCKS_PER_CU) * (int64_t)num_cus();
   if (slots > a.sk_max_blocks) slots = a.sk_max_blocks;
   // Many tiles, or a short K loop (< 32 steps: a split tile's slab hand-off would cost more
   // than the imbalance it removes -- measured): one whole tile per block, the hardware
@@ -997,7 +1010,7 @@ static int launch_conv_pre(const ConvArgs& a, hipStream_t st) {
   b.fd_taps = make_fastdiv(a.KH * a.KW);
   if (a.k_order == 1 && a.Cin % BK != 0) return set_error("conv: channel-block-major K order needs Cin %% 32 == 0");
   b.fd_tiles_n = make_fastdiv((a.Cout + T::BN - 1) / T::BN);
-  hipLaunchKernelGGL(kern, dim3((unsigned)P), dim3(T::NT), T::LDS_BYTES, st, b);
+  hipLaunchKernelGGL(kern, dim3((unsigned)P), dim3(T::NT), lds_bytes, st, b);
   DIF_HIP(hipGetLastError());
   return 0;
 }
@@ -1037,6 +1050,18 @@ int conv_run(const ConvArgs& a, hipStream_t st) {
   // Two tile shapes ship (see the comment above): 64x64 / 4 waves, and 128x128 / 8 waves (each wave 64x32) for
   // layers with a long K loop and at least 128 output channels: half the operand staging, barriers and
   // address arithmetic per MFMA at the same four waves per SIMD.
+  if (a.w3) {
+    // split-bf16 mode (8 waves, 128x128; 256x64 for narrow layers): stream-K / one tile per block as for f32
+    const bool pw = a.KH == 1 && a.KW == 1 && a.pad_t == 0 && a.pad_l == 0 && a.Cin % BK == 0;
+    if (a.Cout <= 64) {
+      using T = Tile<2, 1, 4, 2>;
+      if (pw) return a.pre_scale ? launch_conv_pre<T, true, false, 1, true>(a, st) : launch_conv_pre<T, false, false, 1, true>(a, st);
+      return a.pre_scale ? launch_conv_pre<T, true, false, 0, true>(a, st) : launch_conv_pre<T, false, false, 0, true>(a, st);
+    }
+    using T = Tile<2, 1, 2, 4>;
+    if (pw) return a.pre_scale ? launch_conv_pre<T, true, false, 1, true>(a, st) : launch_conv_pre<T, false, false, 1, true>(a, st);
+    return a.pre_scale ? launch_conv_pre<T, true, false, 0, true>(a, st) : launch_conv_pre<T, false, false, 0, true>(a, st);
+  }
   if (conv_big_tile(a)) return launch_conv<Tile<2, 1, 2, 4>>(a, st);
   return launch_conv<Tile<1, 1>>(a, st);
 }

@@ -812,6 +812,19 @@ static int upload(Net* net, const std::vector<float>& host, float** out) {
   return 0;
 }
 
+static inline uint16_t f32_to_bf16_rne(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)(u >> 16);   // inf / NaN: truncate
+  return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+static inline float bf16_to_f32(uint16_t b) {
+  const uint32_t u = (uint32_t)b << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
 // scale/shift of "(acc + bias) -> BN":  scale = gamma / sqrt(var + eps), shift = beta - mean*scale (+ bias*scale)
 static void fold(const Net* net, const BNRef& bn, int bias, int C, std::vector<float>* scale,
                  std::vector<float>* shift) {
@@ -864,6 +877,27 @@ int Net::finalize(int mb) {
           for (int co = 0; co < op.Cout; ++co) packed[(size_t)co * op.Kpad + kk] = src[co];
         }
       if (upload(this, packed, &op.d_w)) return -1;
+      op.d_w3 = nullptr;
+      if (compute_bf16x3 && op.Cin % BK == 0 && op.Cout >= 32 && op.Cout % 4 == 0) {
+        // split-bf16 mode: hi / mid / lo planes by repeated round-to-nearest-even, [Cout][Kpad/32][3][32]
+        std::vector<uint16_t> w3((size_t)op.Cout * op.Kpad * 3);
+        const int KS = op.Kpad / BK;
+        for (int co = 0; co < op.Cout; ++co)
+          for (int ks = 0; ks < KS; ++ks)
+            for (int k = 0; k < BK; ++k) {
+              float r = packed[(size_t)co * op.Kpad + (size_t)ks * BK + k];
+              for (int p = 0; p < 3; ++p) {
+                const uint16_t b = f32_to_bf16_rne(r);
+                w3[(((size_t)co * KS + ks) * 3 + p) * BK + k] = b;
+                r -= bf16_to_f32(b);
+              }
+            }
+        void* d = nullptr;
+        DIF_HIP(hipMalloc(&d, w3.size() * sizeof(uint16_t) + 64));
+        allocs.push_back(d);
+        DIF_HIP(hipMemcpy(d, w3.data(), w3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        op.d_w3 = d;
+      }
       fold(this, op.bn, op.bias, op.Cout, &scale, &shift);
       if (!scale.empty() && upload(this, scale, &op.d_scale)) return -1;
       if (!shift.empty() && upload(this, shift, &op.d_shift)) return -1;
@@ -1026,6 +1060,7 @@ int Net::run_op(const Op& op, Lane& L, const void* xin, int n, int layout, int d
       memset(&a, 0, sizeof(a));
       a.x = ptr(op.x);
       a.w = op.d_w;
+      a.w3 = op.d_w3;
       a.y = ptr(op.y);
       a.y2 = ptr(op.y2);
       a.scale = op.d_scale;

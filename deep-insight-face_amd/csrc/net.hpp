@@ -60,6 +60,7 @@ struct Op {
   int act = ACT_NONE, act2 = ACT_NONE;
   // device side (filled by finalize)
   float* d_w = nullptr;
+  void* d_w3 = nullptr;       // split-bf16 planes of the same matrix (compute mode bf16x3)
   float* d_scale = nullptr;
   float* d_shift = nullptr;
   float* d_alpha = nullptr;
@@ -118,6 +119,7 @@ struct Net {
   std::vector<int64_t> buf_elems;   // per image
   int sk_max_blocks = 0;
   int sk_spin_limit = 1 << 18;
+  int compute_bf16x3 = 0;           // option "bf16x3" (set before finalize): convolutions on the split-bf16 MFMA path
   int use_pipe = 1;                 // option "pipe": 0 keeps every convolution on conv_igemm_kernel
 
   ~Net();

@@ -41,6 +41,7 @@ inline FastDiv make_fastdiv(int d) {
 struct ConvArgs {
   const float* x;       // [N,H,W,Cin] NHWC
   const float* w;       // packed [Cout][Kpad], zero padded; k order per k_order
+  const void* w3;       // split-bf16 mode: the same matrix as three bf16 planes, [Cout][Kpad/32][3][32] (null: f32 path)
   int k_order;          // 0: k = (kh*KW + kw)*Cin + ci (tap-major)
                         // 1: k = ((ci/32)*KH*KW + kh*KW + kw)*32 + ci%32 (channel-block-major, Cin % 32 == 0):
                         //    consecutive K-steps sweep the taps of ONE 32-channel slice, i.e. re-read the

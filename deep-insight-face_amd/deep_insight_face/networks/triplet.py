@@ -20,7 +20,8 @@ class DifEmbedder:
     """Keras-model stand-in: ``predict_on_batch``, ``__call__``, ``predict``,
     ``load_weights``, ``save_weights`` (networks/inceptionv3.py:73-91, api.py:87)."""
 
-    def __init__(self, arch='resnet', head='v2', emd_size=128, input_shape=(112, 112, 3), max_batch=256, name=None):
+    def __init__(self, arch='resnet', head='v2', emd_size=128, input_shape=(112, 112, 3), max_batch=256, name=None,
+                 compute='f32'):
         if len(input_shape) != 3 or input_shape[2] != 3:
             raise ValueError('input_shape must be (H, W, 3), got %r' % (input_shape,))
         self.arch, self.head, self.emd_size = arch, head, int(emd_size)
@@ -31,6 +32,11 @@ class DifEmbedder:
         N.check(N.lib.dif_net_create(ctypes.byref(self._h), arch.encode(), head.encode(), self.emd_size,
                                      self.input_shape[0], self.input_shape[1]), ValueError)
         self._ready = False
+        if compute not in ('f32', 'bf16x3'):
+            raise ValueError("compute must be 'f32' (the reference's arithmetic) or 'bf16x3' (split-bf16 throughput mode)")
+        self.compute = compute
+        if compute == 'bf16x3':
+            N.check(N.lib.dif_net_set_option(self._h, b'bf16x3', 1), ValueError)
         shp = (ctypes.c_int64 * 3)()
         N.check(N.lib.dif_net_output_dim(self._h, shp))
         c, h, w = int(shp[0]), int(shp[1]), int(shp[2])

@@ -103,3 +103,18 @@ def one_shot_clf(probe, gallery, distance_metric=1):
     (name kept from the reference stub, deep_insight_face/oneshot.py:110)."""
     idx, dist = match(probe, gallery, distance_metric)
     return int(idx[0]), float(dist[0])
+
+
+def cosine_similarity_matrix(embeddings1, embeddings2=None):
+    """All-pairs cosine similarity ``l2norm(E1) @ l2norm(E2).T`` -> [B, G] float32 (E2 defaults to E1):
+    the reference's own "cosine = matmul of normalised rows" (common/losses.py:39-40, :137-138), as one
+    MFMA GEMM with both normalisations in its epilogue (csrc/arcmargin.hip with scale 1, no margin).
+    NumPy in -> NumPy out."""
+    from .networks.arcmargin import ArcMarginHead
+    if embeddings2 is None:
+        embeddings2 = embeddings1
+    head = ArcMarginHead(embeddings2, s=1.0, m=0.0)
+    try:
+        return head.logits(embeddings1)
+    finally:
+        head.close()

@@ -152,7 +152,10 @@ int dif_net_set_input_transform(dif_net* net, float scale, const float bias[3], 
 int dif_net_finalize(dif_net* net, int max_batch);
 /* execution options (no reference counterpart: Keras picks its kernels by itself).  Keys:
  *   "pipe"  1 (default) lets short-K convolutions take the software-pipelined kernel, 0 keeps every
- *           convolution on the plain implicit-GEMM kernel (the two are compared by the parity tests) */
+ *           convolution on the plain implicit-GEMM kernel (the two are compared by the parity tests)
+ *   "bf16x3" 0 (default): float32 MFMA, a bit-exact f32 fma chain -- the reference's arithmetic;
+ *           1 (before dif_net_finalize): throughput mode -- every f32 operand split into three bf16 terms, six
+ *           bf16 MFMA products accumulated in f32 (f32-level accuracy, same 1e-5 cosine gate, not bit-identical) */
 int dif_net_set_option(dif_net* net, const char* key, int value);
 int dif_net_output_dim(const dif_net* net, int64_t shape[3]); /* {emd,1,1} or {C,H,W} for v3 */
 /* networks with several outputs (arch "yolov3": the three detection maps, coarse first; emd_size

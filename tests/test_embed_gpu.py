@@ -305,3 +305,33 @@ def test_embed_full_batch_properties(cuda):
     want = nets.embed(scaled(u8[rows]), p, 'resnet', 512, 'v2')
     assert cosine_gap(full[rows], want).max() < TOL
     model.close()
+
+
+@pytest.mark.parametrize('arch,head,emd,n', [('iresnet50', 'v2', 512, 5), ('iresnet100', 'v2', 512, 3),
+                                             ('resnet', 'v2', 512, 9), ('resnet', 'v1', 128, 4),
+                                             ('vgg16', 'v2', 512, 3)])
+def test_embed_bf16x3_mode_vs_oracle(cuda, arch, head, emd, n):
+    """The split-bf16 throughput mode (dif_net_set_option "bf16x3": three bf16 terms per f32 operand, six MFMA
+    products, f32 accumulation) against the same oracle at the same gates as the float32 path: cosine gap
+    < 1e-5, pairwise cosine distances within 1e-5; and against the f32 path itself."""
+    from deep_insight_face.networks.triplet import DifEmbedder
+    x = scaled(crops_u8(n, seed=31))
+    f32 = DifEmbedder(arch, head, emd, (112, 112, 3), max_batch=n).init_synthetic(2024)
+    b3 = DifEmbedder(arch, head, emd, (112, 112, 3), max_batch=n, compute='bf16x3')
+    p = f32.get_weights()
+    b3.set_weights(p)
+    got = b3.predict_on_batch(x)
+    ref = f32.predict_on_batch(x)
+    want = nets.embed(x, p, arch, emd, head)
+    assert np.all(np.isfinite(got))
+    assert cosine_gap(got, want).max() < TOL
+    assert cosine_gap(got, ref).max() < 1e-6
+    np.testing.assert_allclose(got, want, atol=2e-4 * np.abs(want).max(), rtol=2e-3)
+    for i in range(n):
+        a = od.distance(np.repeat(got[i][None], n, 0), got, 1)
+        b = od.distance(np.repeat(want[i][None], n, 0), want, 1)
+        mask = np.arange(n) != i
+        np.testing.assert_allclose(a[mask], b[mask], atol=TOL)
+    assert np.array_equal(b3.predict_on_batch(x), got)            # deterministic
+    f32.close()
+    b3.close()

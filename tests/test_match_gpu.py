@@ -337,3 +337,19 @@ def test_match_exact_search_on_overflow(cuda):
         oi2, _, _ = od.match(np.concatenate([probes[:2], clean]), gal_np, 1)
     assert np.array_equal(i2, oi2)
     gal.close()
+
+
+def test_cosine_similarity_matrix(cuda):
+    """the all-pairs cosine matrix of common/losses.py:39-40 as an entry point."""
+    from deep_insight_face import oneshot
+    rng = np.random.default_rng(8)
+    a = (rng.standard_normal((70, 512)) * rng.uniform(0.2, 5, (70, 1))).astype(np.float32)
+    b = (rng.standard_normal((333, 512)) * rng.uniform(0.2, 5, (333, 1))).astype(np.float32)
+    an = a / np.linalg.norm(a, axis=1, keepdims=True)
+    bn = b / np.linalg.norm(b, axis=1, keepdims=True)
+    got = oneshot.cosine_similarity_matrix(a, b)
+    assert got.shape == (70, 333) and got.dtype == np.float32
+    np.testing.assert_allclose(got, an.astype(np.float64) @ bn.astype(np.float64).T, atol=2e-6)
+    self_sim = oneshot.cosine_similarity_matrix(torch.from_numpy(a).cuda())
+    assert torch.is_tensor(self_sim) and self_sim.shape == (70, 70)
+    np.testing.assert_allclose(np.diag(self_sim.cpu().numpy()), 1.0, atol=2e-6)

@@ -12,11 +12,12 @@ from deep_insight_face.networks.triplet import DifEmbedder  # noqa: E402
 def main():
     arch = sys.argv[1] if len(sys.argv) > 1 else 'resnet'
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+    compute = sys.argv[3] if len(sys.argv) > 3 else 'f32'
     if arch == 'yolov3':
         m = DifEmbedder('yolov3', 'v3', 1, (416, 416, 3), max_batch=B).init_synthetic()
         x = torch.randint(0, 256, (B, 416, 416, 3), dtype=torch.uint8, device='cuda')
     else:
-        m = DifEmbedder(arch, 'v2', 512, (112, 112, 3), max_batch=B).init_synthetic()
+        m = DifEmbedder(arch, 'v2', 512, (112, 112, 3), max_batch=B, compute=compute).init_synthetic()
         x = torch.randint(0, 256, (B, 112, 112, 3), dtype=torch.uint8, device='cuda')
     for _ in range(2):
         m.embed(x)
