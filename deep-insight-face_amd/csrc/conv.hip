@@ -505,13 +505,13 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const 
       if constexpr (BF3)
         gemm_mainloop_bf3<T>(al, bl, k0, k1, reinterpret_cast<char*>(smem), acc, [&] {
           if (prefetch_res && a.res) er.load(a, m0, n0);
-        });
+        }, a.dbg);
       else if constexpr (DMA)
         gemm_mainloop_dma<T>(al, bl, k0, k1, smem, acc);
       else
         gemm_mainloop2<T>(al, bl, k0, k1, smem, acc, [&] {
           if (prefetch_res && a.res) er.load(a, m0, n0);
-        });
+        }, a.dbg);
     };
     run(kb, ke, whole);
     const unsigned long long tB = a.trace ? __builtin_amdgcn_s_memrealtime() : 0;
@@ -974,8 +974,9 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
 template <class T, bool PRE, bool DMA, int AM, bool BF3>
 static int launch_conv_pre(const ConvArgs& a, hipStream_t st) {
   auto kern = conv_igemm_kernel<T, PRE, DMA, AM, BF3>;
-  constexpr int lds_bytes = BF3 ? Bf3<T>::LDS_BYTES : T::LDS_BYTES;
-  if (allow_dynamic_lds(kern, lds_bytes)) return -1;
+  static const int lds_pad = getenv("DIF_CONV_LDS_PAD") ? atoi(getenv("DIF_CONV_LDS_PAD")) : 0;   // experiment: fewer blocks per CU
+  const int lds_bytes = (BF3 ? Bf3<T>::LDS_BYTES : T::LDS_BYTES) + lds_pad;
+  if (allow_dynamic_lds(kern, lds_bytes + 16384)) return -1;
   const int64_t tiles = ((a.M + T::BM - 1) / T::BM) * (int64_t)((a.Cout + T::BN - 1) / T::BN);
   const int KS = a.Kpad / BK;
   const int64_t I = tiles * KS;
@@ -1010,9 +1011,24 @@ static int launch_conv_pre(const ConvArgs& a, hipStream_t st) {
   b.fd_taps = make_fastdiv(a.KH * a.KW);
   if (a.k_order == 1 && a.Cin % BK != 0) return set_error("conv: channel-block-major K order needs Cin %% 32 == 0");
   b.fd_tiles_n = make_fastdiv((a.Cout + T::BN - 1) / T::BN);
+  static const int dbg = getenv("DIF_CONV_DBG") ? atoi(getenv("DIF_CONV_DBG")) : 0;   // development aid (ablations)
+  b.dbg = dbg;
   hipLaunchKernelGGL(kern, dim3((unsigned)P), dim3(T::NT), lds_bytes, st, b);
   DIF_HIP(hipGetLastError());
   return 0;
+}
+
+// Split-bf16 pays where a block gets a long run of K-steps: its tiles are four times the f32 kernel's and it
+// has no pipelined epilogue, so layers with a short K loop or few tiles stay on the f32 kernels even in
+// bf16x3 mode (measured: ResNet50V2's pointwise layers and IResNet's 1x1 downsample / fc lose, every 3x3 layer
+// from 128 channels up gains 1.3-1.5x).  DIF_BF3_MIN_KS / DIF_BF3_MIN_RUN move the thresholds.
+static bool bf3_pays(const ConvArgs& a) {
+  static const int min_ks = getenv("DIF_BF3_MIN_KS") ? atoi(getenv("DIF_BF3_MIN_KS")) : 9;
+  static const int min_run = getenv("DIF_BF3_MIN_RUN") ? atoi(getenv("DIF_BF3_MIN_RUN")) : 24;
+  const int KS = a.Kpad / BK;
+  const int bm = a.Cout <= 64 ? 256 : 128, bn = a.Cout <= 64 ? 64 : 128;
+  const int64_t tiles = ((a.M + bm - 1) / bm) * (int64_t)((a.Cout + bn - 1) / bn);
+  return KS >= min_ks && tiles * KS >= (int64_t)min_run * 2 * num_cus();
 }
 
 static bool conv_big_tile(const ConvArgs& a) {
@@ -1050,7 +1066,7 @@ int conv_run(const ConvArgs& a, hipStream_t st) {
   // Two tile shapes ship (see the comment above): 64x64 / 4 waves, and 128x128 / 8 waves (each wave 64x32) for
   // layers with a long K loop and at least 128 output channels: half the operand staging, barriers and
   // address arithmetic per MFMA at the same four waves per SIMD.
-  if (a.w3) {
+  if (a.w3 && bf3_pays(a)) {
     // split-bf16 mode (8 waves, 128x128; 256x64 for narrow layers): stream-K / one tile per block as for f32
     const bool pw = a.KH == 1 && a.KW == 1 && a.pad_t == 0 && a.pad_l == 0 && a.Cin % BK == 0;
     if (a.Cout <= 64) {

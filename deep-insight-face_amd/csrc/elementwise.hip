@@ -300,6 +300,98 @@ int dwfull_run(const float* x, const float* w, const float* scale, const float* 
   return 0;
 }
 
+// ---------------------------------------------------------------- GDC tail, fused
+// networks/triplet.py:129-138 after the head's first convolution: DepthwiseConv2D(kernel = whole map) -> BN ->
+// Conv2D(emd, 1) -> Dropout (identity) -> Flatten -> Dense(emd) -> l2_normalize, two images per block.  About
+// 0.5 MMAC per image against 2 MB of weights that stay in L2: bound by launch and latency, so what matters is
+// that it is ONE launch (it was four) and that the weight reads are coalesced along the output axis.
+__global__ __launch_bounds__(256) void gdc_tail_kernel(const float* __restrict__ x, const float* __restrict__ wdw,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       const float* __restrict__ wpw, const float* __restrict__ wd,
+                                                       float* __restrict__ y, int N, int HW, int E, float eps) {
+  constexpr int C = 512;
+  __shared__ float a[2][C];
+  __shared__ float b[2][1024];
+  __shared__ float red[2][4];
+  const int tid = threadIdx.x;
+  const int64_t n0 = (int64_t)blockIdx.x * 2;
+  const bool two = n0 + 1 < N;
+  const float* x0 = x + n0 * HW * C;
+  const float* x1 = x + (two ? n0 + 1 : n0) * HW * C;
+  for (int c = tid; c < C; c += 256) {
+    float s0 = 0.f, s1 = 0.f;
+    for (int p = 0; p < HW; ++p) {
+      const float w = wdw[p * C + c];
+      s0 = fmaf(x0[p * C + c], w, s0);
+      s1 = fmaf(x1[p * C + c], w, s1);
+    }
+    const float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
+    a[0][c] = fmaf(s0, sc, sh);
+    a[1][c] = fmaf(s1, sc, sh);
+  }
+  __syncthreads();
+  for (int j = tid; j < E; j += 256) {
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < C; ++c) {
+      const float w = wpw[(int64_t)c * E + j];
+      s0 = fmaf(a[0][c], w, s0);
+      s1 = fmaf(a[1][c], w, s1);
+    }
+    b[0][j] = s0;
+    b[1][j] = s1;
+  }
+  __syncthreads();
+  float o0[4], o1[4], ss0 = 0.f, ss1 = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int j = tid + 256 * q;
+    float s0 = 0.f, s1 = 0.f;
+    if (j < E) {
+#pragma unroll 8
+      for (int i = 0; i < E; ++i) {
+        const float w = wd[(int64_t)i * E + j];
+        s0 = fmaf(b[0][i], w, s0);
+        s1 = fmaf(b[1][i], w, s1);
+      }
+    }
+    o0[q] = s0;
+    o1[q] = s1;
+    ss0 = fmaf(s0, s0, ss0);
+    ss1 = fmaf(s1, s1, ss1);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ss0 += __shfl_xor(ss0, o);
+    ss1 += __shfl_xor(ss1, o);
+  }
+  if ((tid & 63) == 0) {
+    red[0][tid >> 6] = ss0;
+    red[1][tid >> 6] = ss1;
+  }
+  __syncthreads();
+  const float inv0 = 1.f / sqrtf(fmaxf(red[0][0] + red[0][1] + red[0][2] + red[0][3], eps));
+  const float inv1 = 1.f / sqrtf(fmaxf(red[1][0] + red[1][1] + red[1][2] + red[1][3], eps));
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int j = tid + 256 * q;
+    if (j < E) {
+      y[n0 * E + j] = o0[q] * inv0;
+      if (two) y[(n0 + 1) * E + j] = o1[q] * inv1;
+    }
+  }
+}
+
+int gdc_tail_run(const float* x, const float* w_dw, const float* scale, const float* shift, const float* w_pw,
+                 const float* w_dense, float* y, int N, int HW, int E, float eps, hipStream_t st) {
+  if (N == 0) return 0;
+  if (E > 1024) return set_error("gdc_tail: emd %d > 1024", E);
+  hipLaunchKernelGGL(gdc_tail_kernel, dim3((unsigned)((N + 1) / 2)), dim3(256), 0, st, x, w_dw, scale, shift, w_pw, w_dense,
+                     y, N, HW, E, eps);
+  DIF_HIP(hipGetLastError());
+  return 0;
+}
+
 // ---------------------------------------------------------------- row-wise L2 normalisation
 // tf.nn.l2_normalize(axis=1) (networks/triplet.py:138): x * rsqrt(max(sum(x^2), 1e-12)); one wave per row.
 __global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x, float* __restrict__ y, int N,

@@ -152,7 +152,7 @@ __device__ __forceinline__ void gemm_mainloop(ALoader& al, BLoader& bl, int kbeg
 // 128-VGPR budget of four waves per SIMD it spills, and loses 5-35 % on every layer class.)
 template <class T, class ALoader, class BLoader, class Tail>
 __device__ __forceinline__ void gemm_mainloop2(ALoader& al, BLoader& bl, int kbeg, int kend, float* lds,
-                                               f32x16 (&acc)[T::WM][T::WN], Tail&& tail) {
+                                               f32x16 (&acc)[T::WM][T::WN], Tail&& tail, int dbg = 0) {
   constexpr int WM = T::WM, WN = T::WN, BM = T::BM, BN = T::BN, NA = T::NA, NB = T::NB, RP = T::RP;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -188,11 +188,13 @@ __device__ __forceinline__ void gemm_mainloop2(ALoader& al, BLoader& bl, int kbe
                                                              acc[m][n], 0, 0, 0);
     }
   };
-  auto stage = [&](int buf, f32x4 (&ra)[NA], f32x4 (&rb)[NB]) {
+  auto stage = [&](int buf, f32x4 (&ra)[NA], f32x4 (&rb)[NB], bool with_a = true) {
     float* wa = lds + buf * BUF + st_off;
-    al.finish(ra);
+    if (with_a) {
+      al.finish(ra);
 #pragma unroll
-    for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(wa + i * RP * LDS_STRIDE) = ra[i];
+      for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(wa + i * RP * LDS_STRIDE) = ra[i];
+    }
 #pragma unroll
     for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(wa + OFFB + i * RP * LDS_STRIDE) = rb[i];
   };
@@ -205,14 +207,17 @@ __device__ __forceinline__ void gemm_mainloop2(ALoader& al, BLoader& bl, int kbe
   int ks = kbeg;
   for (; ks + 1 < kend; ++ks) {
     const int cur = (ks - kbeg) & 1;
-    al.load(ks + 1, ra);
+    // (ablation, DIF_CONV_DBG=32: the A operand is fetched and staged on one K-step in nine only -- results
+    // are wrong on purpose; it prices what a halo-resident A patch could save)
+    const bool with_a = !(dbg & 32) || ((ks + 1) % 9 == 0);
+    if (with_a) al.load(ks + 1, ra);
     bl.load(ks + 1, rb);
     // keep the prefetch where it is written: left alone, the scheduler sinks these loads below the
     // MFMAs, right in front of the LDS writes that consume them, and the loop stops overlapping
     // global-load latency with matrix work at all
     __builtin_amdgcn_sched_barrier(0);
     mfma_step(cur);
-    stage(cur ^ 1, ra, rb);
+    stage(cur ^ 1, ra, rb, with_a);
     __syncthreads();
   }
   tail();
@@ -326,7 +331,7 @@ struct Bf3WeightLoader {
 
 template <class T, class ALoader, class BLoader, class Tail>
 __device__ __forceinline__ void gemm_mainloop_bf3(ALoader& al, BLoader& bl, int kbeg, int kend, char* lds,
-                                                  f32x16 (&acc)[T::WM][T::WN], Tail&& tail) {
+                                                  f32x16 (&acc)[T::WM][T::WN], Tail&& tail, int dbg = 0) {
   constexpr int WM = T::WM, WN = T::WN, NA = T::NA, RP = T::RP;
   constexpr int OFFB = T::BM * BF3_ROWB;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -365,6 +370,10 @@ __device__ __forceinline__ void gemm_mainloop_bf3(ALoader& al, BLoader& bl, int 
 #pragma unroll
         for (int p = 0; p < 3; ++p)
           fb[n][p] = *reinterpret_cast<const bf16x8*>(pb + n * 32 * BF3_ROWB + p * 64 + s * 32);
+      // all fragment reads of the sub-step are in flight before its first MFMA: left alone, the scheduler
+      // recycles four fragment registers and puts a full LDS round trip (s_waitcnt lgkmcnt(0)) in front of
+      // almost every MFMA
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int m = 0; m < WM; ++m)
 #pragma unroll
@@ -384,12 +393,14 @@ __device__ __forceinline__ void gemm_mainloop_bf3(ALoader& al, BLoader& bl, int 
   bl.load(kbeg, rb);
   int ks = kbeg;
   for (; ks + 1 < kend; ++ks) {
-    stage();
+    if (!(dbg & 16)) stage();
     __syncthreads();
-    al.load(ks + 1, ra);
-    bl.load(ks + 1, rb);
+    if (!(dbg & 4)) {              // (ablation switches, DIF_CONV_DBG: 4 no global loads, 8 no MFMAs, 16 no staging)
+      al.load(ks + 1, ra);
+      bl.load(ks + 1, rb);
+    }
     __builtin_amdgcn_sched_barrier(0);   // the prefetch stays above the MFMAs
-    mfma_step();
+    if (!(dbg & 8)) mfma_step();
     __syncthreads();   // every wave is done reading before the next K-step overwrites the image
   }
   // last K-step peeled: the caller's tail loads (the shortcut tile) hide behind its MFMAs, and their

@@ -260,6 +260,28 @@ int Net::build_heads(int feat) {
                  nullptr);
     // triplet.py:129-130  DepthwiseConv2D(kernel = map size) -> BN
     if (fd.H != fd.W) return set_error("GDC head needs a square feature map (got %dx%d)", fd.H, fd.W);
+    static const bool fuse_tail = !(getenv("DIF_NO_TAIL_FUSION") && atoi(getenv("DIF_NO_TAIL_FUSION")));
+    if (fuse_tail && emd <= 1024) {
+      // triplet.py:129-138 in ONE launch: depthwise over the whole map + BN -> Conv1x1(emd) ->
+      // [Dropout = identity] -> Flatten -> Dense(emd) -> l2_normalize.  0.5 MMAC per image: latency, not MFMA work.
+      Op g;
+      g.kind = OP_GDCTAIL;
+      g.name = "head_tail";
+      g.x = h;
+      g.KH = fd.H;
+      g.KW = fd.W;
+      g.Cin = 512;
+      g.Cout = emd;
+      g.w = P("head_dw/depthwise_kernel", {fd.H, fd.W, 512, 1});
+      g.bn = BN("head_bn2", 512, EPS_KERAS);
+      g.w_pw = P("head_pw/kernel", {1, 1, 512, emd});
+      g.w_dense = P("head_dense/kernel", {emd, emd});
+      g.y = T(1, 1, emd);
+      g.macs = (double)fd.H * fd.W * 512 + 512.0 * emd + (double)emd * emd;
+      ops.push_back(g);
+      output_tensor = g.y;
+      return 0;
+    }
     Op d;
     d.kind = OP_DWFULL;
     d.name = "head_dw";
@@ -905,6 +927,13 @@ int Net::finalize(int mb) {
       if (op.alpha < 0 && op.const_alpha != 0.f &&
           upload(this, std::vector<float>((size_t)op.Cout, op.const_alpha), &op.d_alpha))
         return -1;
+    } else if (op.kind == OP_GDCTAIL) {
+      if (upload(this, params[op.w].data, &op.d_w)) return -1;            // [HW][512]
+      if (upload(this, params[op.w_pw].data, &op.d_w_pw)) return -1;      // [512][emd]
+      if (upload(this, params[op.w_dense].data, &op.d_w_dense)) return -1;   // [emd][emd]
+      fold(this, op.bn, -1, op.Cin, &scale, &shift);
+      if (!scale.empty() && upload(this, scale, &op.d_scale)) return -1;
+      if (!shift.empty() && upload(this, shift, &op.d_shift)) return -1;
     } else if (op.kind == OP_DWFULL || op.kind == OP_DWCONV) {
       if (upload(this, params[op.w].data, &op.d_w)) return -1;   // [H][W][C][1] == [HW][C]
       fold(this, op.bn, -1, op.Cout, &scale, &shift);
@@ -1017,6 +1046,7 @@ const char* Net::kernel_name(const Op& op, int n) const {
     case OP_INPUT: return "input_convert_kernel";
     case OP_MAXPOOL: return "maxpool_kernel";
     case OP_DWFULL: return "dwfull_kernel";
+    case OP_GDCTAIL: return "gdc_tail_kernel";
     case OP_DWCONV: return "dwconv_kernel";
     case OP_L2NORM: return "l2norm_kernel";
     case OP_LRN: return "lrn_kernel";
@@ -1165,6 +1195,13 @@ int Net::run_op(const Op& op, Lane& L, const void* xin, int n, int layout, int d
         a.y_oy = a.y_ox = 0;
       }
       if (maxpool_run(a, st)) return -1;
+      break;
+    }
+    case OP_GDCTAIL: {
+      const TensorDesc& xd = tensors[op.x];
+      if (gdc_tail_run(ptr(op.x), op.d_w, op.d_scale, op.d_shift, op.d_w_pw, op.d_w_dense, ptr(op.y), n, xd.H * xd.W,
+                       op.Cout, 1e-12f, st))
+        return -1;
       break;
     }
     case OP_DWFULL: {

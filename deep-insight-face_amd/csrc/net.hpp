@@ -37,7 +37,8 @@ struct TensorDesc {
   int64_t elems() const { return (int64_t)H * W * C; }
 };
 
-enum OpKind { OP_INPUT, OP_CONV, OP_MAXPOOL, OP_DWFULL, OP_L2NORM, OP_LRN, OP_ZERO, OP_UPSAMPLE, OP_COPY, OP_DWCONV };
+enum OpKind { OP_INPUT, OP_CONV, OP_MAXPOOL, OP_DWFULL, OP_L2NORM, OP_LRN, OP_ZERO, OP_UPSAMPLE, OP_COPY, OP_DWCONV,
+              OP_GDCTAIL };
 
 struct Op {
   OpKind kind = OP_CONV;
@@ -54,12 +55,15 @@ struct Op {
   int k_order = 0;            // see ConvArgs::k_order   // dense after an NCHW-order flatten: permute kernel rows at pack time
   // parameters
   int w = -1, bias = -1, alpha = -1, alpha2 = -1;
+  int w_pw = -1, w_dense = -1;   // OP_GDCTAIL: the 1x1 convolution and the dense layer behind the depthwise one
   BNRef bn, bn2;
   BNRef pre_bn;               // pre-activation BN applied to the input while it is gathered
   int pre_act = ACT_NONE;
   int act = ACT_NONE, act2 = ACT_NONE;
   // device side (filled by finalize)
   float* d_w = nullptr;
+  float* d_w_pw = nullptr;
+  float* d_w_dense = nullptr;
   void* d_w3 = nullptr;       // split-bf16 planes of the same matrix (compute mode bf16x3)
   float* d_scale = nullptr;
   float* d_shift = nullptr;

@@ -132,6 +132,10 @@ int dwconv_run(const float* x, const float* w, const float* scale, const float* 
 // depthwise conv whose kernel covers the whole map, + BN: y[n,c] = (sum_hw x*w) * scale + shift
 int dwfull_run(const float* x, const float* w, const float* scale, const float* shift, float* y, int N, int HW,
                int C, hipStream_t st);
+// GDC head tail in one launch (networks/triplet.py:129-138): depthwise over the whole map + BN -> 1x1 conv (512 -> E) ->
+// dense (E -> E) -> l2_normalize; x [N][HW][512], w_dw [HW][512], w_pw [512][E], w_dense [E][E], y [N][E]; E <= 1024
+int gdc_tail_run(const float* x, const float* w_dw, const float* scale, const float* shift, const float* w_pw,
+                 const float* w_dense, float* y, int N, int HW, int E, float eps, hipStream_t st);
 // y = x * rsqrt(max(sum(x^2), eps)) per row
 int l2norm_run(const float* x, float* y, int N, int D, float eps, hipStream_t st);
 
