@@ -304,6 +304,167 @@ struct ConvADmaLoader {
   }
 };
 
+// ------------------------------------------------------------------------------------------
+// Halo-resident A operand for 3x3 / stride 1 / pad 1 layers ("patch" path, AM = 3).
+//
+// The general gather above re-fetches and re-stages the A tile on EVERY K-step, although the nine taps of a
+// 32-channel slice read (shifted copies of) the same input pixels: per slice, 9 x 64 rows x 128 B pass through
+// the vector memory path, the staging registers and the LDS write port.  Measured on IResNet-100's 3x3 layers
+// (DIF_CONV_DBG=32 ablation, profiles/r02_ablation.txt): that costs 11 % of the layer time, and it is where the
+// 2.4x excess of fabric traffic over the compulsory bytes came from.
+//
+// Here the tile's input pixels -- its own 64 pixels plus the halo above, below and beside them -- are laid in
+// LDS ONCE per 32-channel slice, in padded image coordinates
+//        P(n, h, w) = (n * (H + 1) + h + 1) * (W + 2) + (w + 1)
+// (one zero column each side of a row, one zero row shared by consecutive images), so that the operand row of
+// output pixel i for tap (kh, kw) is simply entry  base_i + kh * (W + 2) + kw:  a tap is an ADDRESS OFFSET.
+// Entries are 128 bytes (32 floats) without padding; bank conflicts of the fragment reads are removed by the XOR
+// swizzle chunk' = chunk ^ ((entry >> 1) & 7) (cdna_hip_programming.md rule 21), applied when an entry is written
+// and when it is read.  The B tile uses the same unpadded swizzled rows, so a block needs
+// PATCH_EMAX * 128 + 2 * 64 * 128 = 37.9 KB of LDS: four blocks per CU, as before.
+// The next slice's patch is fetched into registers while taps 4..8 of the current one run, and written after a
+// barrier at the slice boundary (one extra barrier per nine K-steps).
+constexpr int PATCH_EMAX = 168;                       // entries a 64-pixel tile may need (host-checked bound)
+constexpr int PATCH_NPC = (PATCH_EMAX * 8 + 255) / 256;   // 16-byte chunks per thread per patch
+constexpr int PATCH_LDS_BYTES = PATCH_EMAX * 128 + 2 * 64 * 128;
+constexpr int PATCH_PF_TAP = 4;                       // tap of the current slice at which the next patch is requested
+
+__device__ __forceinline__ int patch_swz(int entry) { return (entry >> 1) & 7; }
+
+struct PatchA {
+  __amdgpu_buffer_rsrc_t rsrc;
+  uint32_t goff[PATCH_NPC];   // byte offset of this thread's chunk j inside channel slice 0, or OOB
+  int base;                   // entry of this lane's output pixel (row lane & 31 of the wave's 32 rows) for tap (0, 0)
+  int WP;
+  __device__ __forceinline__ PatchA(const ConvArgs& a, int m0) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int HW = a.H * a.W;
+    WP = a.W + 2;
+    const int RPI = a.H + 1;
+    int n_first, r0;
+    a.fd_howo.divmod(m0, n_first, r0);
+    const int64_t img_elems = (int64_t)HW * a.Cin;
+    const int64_t imgs_left = a.N - n_first;
+    int64_t span = (64 + HW - 1) / HW + 1;
+    if (span > imgs_left) span = imgs_left;
+    rsrc = make_rsrc(a.x + n_first * img_elems, (uint32_t)(span * img_elems * 4));
+    int h0, w0;
+    a.fd_wo.divmod(r0, h0, w0);
+    const int p_first = (h0 + 1) * WP + (w0 + 1);      // P(m0), images counted from n_first
+    const int origin = p_first - WP - 1;                // tap (0, 0) of the first pixel
+    // this lane's output pixel
+    {
+      const int wr = (tid >> 6) >> 1;                    // Tile<1,1,2,2>: wave row
+      int m = m0 + wr * 32 + (lane & 31);
+      if (m >= a.M) m = m0;
+      int n, r, h, w;
+      a.fd_howo.divmod(m, n, r);
+      a.fd_wo.divmod(r, h, w);
+      base = ((n - n_first) * RPI + h + 1) * WP + (w + 1) - p_first;
+    }
+    // this thread's chunks of the patch
+#pragma unroll
+    for (int j = 0; j < PATCH_NPC; ++j) {
+      const int slot = tid + 256 * j;
+      const int e = slot >> 3, q = slot & 7;
+      const int c = origin + e;                          // padded linear coordinate
+      int row, col, img, hp;
+      a.fd_wp.divmod(c, row, col);
+      a.fd_rpi.divmod(row, img, hp);
+      const bool ok = e < PATCH_EMAX && hp >= 1 && col >= 1 && col <= a.W && (n_first + img) < a.N;
+      const int chunk = q ^ patch_swz(e);                // logical 4-channel chunk that lives in this physical slot
+      goff[j] = ok ? (uint32_t)(((img * a.H + (hp - 1)) * a.W + (col - 1)) * a.Cin * 4 + chunk * 16) : OOB;
+    }
+  }
+  __device__ __forceinline__ void load(int cblk, f32x4 (&r)[PATCH_NPC]) const {
+#pragma unroll
+    for (int j = 0; j < PATCH_NPC; ++j) r[j] = buf_load4(rsrc, goff[j] == OOB ? OOB : goff[j] + (uint32_t)cblk * 128u);
+  }
+  __device__ __forceinline__ void store(float* patch, const f32x4 (&r)[PATCH_NPC]) const {
+#pragma unroll
+    for (int j = 0; j < PATCH_NPC; ++j) {
+      const int slot = threadIdx.x + 256 * j;
+      if (slot < PATCH_EMAX * 8) *reinterpret_cast<f32x4*>(patch + slot * 4) = r[j];
+    }
+  }
+};
+
+// Mainloop of the patch path: K-step ks = (channel slice ks / 9, tap ks % 9) -- the channel-block-major K order.
+// 64x64 tile, 4 waves (Tile<1,1,2,2>).  Ends on a barrier.
+template <class T, class BLoader, class Tail>
+__device__ __forceinline__ void gemm_mainloop_patch(const PatchA& pa, BLoader& bl, int kbeg, int kend, float* lds,
+                                                    f32x16 (&acc)[1][1], Tail&& tail) {
+  static_assert(T::BM == 64 && T::BN == 64 && T::NT == 256, "patch path: 64x64 tile");
+  constexpr int NB = T::NB, RP = T::RP;
+  float* patch = lds;
+  float* bimg = lds + PATCH_EMAX * 32;                   // two B images of 64 rows x 32 floats
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wc = T::wave_col();
+  const int h = lane >> 5;
+  // B staging slot (row tid>>3 + RP*i, logical chunk tid&7) and fragment row
+  const int rb_row = wc * 32 + (lane & 31);
+  const int rb_swz = patch_swz(rb_row);
+  const float* pb0 = bimg + rb_row * 32;
+
+  f32x4 pr[PATCH_NPC], rb[NB];
+  int cb = kbeg / 9, tap = kbeg - cb * 9;
+  pa.load(cb, pr);
+  bl.load(kbeg, rb);
+  auto stage_b = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int row = (tid >> 3) + RP * i;
+      *reinterpret_cast<f32x4*>(bimg + buf * (64 * 32) + row * 32 + (((tid & 7) ^ patch_swz(row)) << 2)) = rb[i];
+    }
+  };
+  pa.store(patch, pr);
+  stage_b(0);
+  __syncthreads();
+  bool pf_issued = false;
+  auto mfma_step = [&](int cur) {
+    const int kh = tap >= 6 ? 2 : (tap >= 3 ? 1 : 0);
+    const int e = pa.base + kh * pa.WP + (tap - 3 * kh);
+    const int sa = patch_swz(e);
+    const float* pae = patch + e * 32;
+    const float* pbe = pb0 + cur * (64 * 32);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int l0 = 2 * h + 4 * s;                        // logical chunks l0, l0 + 1 (k = 16 s + 8 h .. + 7)
+      const f32x4 fa0 = *reinterpret_cast<const f32x4*>(pae + ((l0 ^ sa) << 2));
+      const f32x4 fa1 = *reinterpret_cast<const f32x4*>(pae + (((l0 + 1) ^ sa) << 2));
+      const f32x4 fb0 = *reinterpret_cast<const f32x4*>(pbe + ((l0 ^ rb_swz) << 2));
+      const f32x4 fb1 = *reinterpret_cast<const f32x4*>(pbe + (((l0 + 1) ^ rb_swz) << 2));
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[t], fb0[t], acc[0][0], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[t], fb1[t], acc[0][0], 0, 0, 0);
+    }
+  };
+  int ks = kbeg;
+  for (; ks + 1 < kend; ++ks) {
+    const int cur = (ks - kbeg) & 1;
+    bl.load(ks + 1, rb);
+    if (!pf_issued && tap >= PATCH_PF_TAP && (cb + 1) * 9 < kend) {
+      pa.load(cb + 1, pr);                                 // lands while taps PF_TAP .. 8 run
+      pf_issued = true;
+    }
+    __builtin_amdgcn_sched_barrier(0);                     // the prefetches stay above the MFMAs
+    mfma_step(cur);
+    stage_b(cur ^ 1);
+    if (++tap == 9) {
+      tap = 0;
+      ++cb;
+      __syncthreads();                                     // every wave has read its last fragment of the old patch
+      pa.store(patch, pr);     // pf_issued holds here: the slice had a successor, so its taps >= PF_TAP requested it
+      pf_issued = false;
+    }
+    __syncthreads();
+  }
+  tail();
+  mfma_step((ks - kbeg) & 1);
+  __syncthreads();
+}
+
 __device__ __forceinline__ float apply_act(float v, int act, float alpha) {
   if (act == ACT_RELU) return fmaxf(v, 0.f);
   if (act == ACT_PRELU) return v >= 0.f ? v : v * alpha;
@@ -439,6 +600,7 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const 
   static_assert(!(PRE && DMA), "pre-activation needs register staging");
   static_assert(!(AM != 0 && DMA), "the specialised loaders are register-staged");
   static_assert(!(BF3 && DMA), "the split-bf16 mainloop stages through registers");
+  static_assert(AM != 3 || (!PRE && !DMA && !BF3 && T::BM == 64 && T::BN == 64), "patch path: plain f32, 64x64 tile");
   constexpr int WM = T::WM, WN = T::WN;
   constexpr int SLAB = T::BM * T::BN;    // floats per partial-accumulator slab
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -488,7 +650,8 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const 
     // pre-activation needs the operand in registers; everything else streams through LDS-DMA
     using ALoadReg = typename std::conditional<AM == 1, ConvPwLoader<T::NA, T::RP, PRE>,
                                                ConvALoader<T::NA, T::RP, PRE, AM == 2 ? 2 : 0>>::type;
-    using ALoad = typename std::conditional<DMA, ConvADmaLoader<T::NA, T::RP>, ALoadReg>::type;
+    using ALoadGather = typename std::conditional<DMA, ConvADmaLoader<T::NA, T::RP>, ALoadReg>::type;
+    using ALoad = typename std::conditional<AM == 3, PatchA, ALoadGather>::type;     // AM 3: halo-resident patch
     using BLoadF32 = typename std::conditional<DMA, DmaRowLoader<T::NB, T::RP>, RowLoader<T::NB, T::RP>>::type;
     using BLoad = typename std::conditional<BF3, Bf3WeightLoader<T>, BLoadF32>::type;
     ALoad al(a, m0);
@@ -505,13 +668,17 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const 
       if constexpr (BF3)
         gemm_mainloop_bf3<T>(al, bl, k0, k1, reinterpret_cast<char*>(smem), acc, [&] {
           if (prefetch_res && a.res) er.load(a, m0, n0);
-        }, a.dbg);
+        });
+      else if constexpr (AM == 3)
+        gemm_mainloop_patch<T>(al, bl, k0, k1, smem, acc, [&] {
+          if (prefetch_res && a.res) er.load(a, m0, n0);
+        });
       else if constexpr (DMA)
         gemm_mainloop_dma<T>(al, bl, k0, k1, smem, acc);
       else
         gemm_mainloop2<T>(al, bl, k0, k1, smem, acc, [&] {
           if (prefetch_res && a.res) er.load(a, m0, n0);
-        }, a.dbg);
+        });
     };
     run(kb, ke, whole);
     const unsigned long long tB = a.trace ? __builtin_amdgcn_s_memrealtime() : 0;
@@ -924,6 +1091,19 @@ static int launch_conv_pipe(const ConvArgs& a, hipStream_t st) {
   return 0;
 }
 
+// 3x3 / stride 1 / pad 1, whole 32-channel slices in channel-block-major K order, plain output geometry, and a
+// 64-pixel tile's halo patch bounded by PATCH_EMAX entries (row wraps add 2 entries each, an image boundary adds
+// one padded row).  IResNet's 28x28, 14x14 and 7x7 stages qualify; 56x56 and up keep the per-K-step gather.
+static bool patch_applies(const ConvArgs& a) {
+  static const bool on = !(getenv("DIF_NO_PATCH") && atoi(getenv("DIF_NO_PATCH")));
+  if (!on || a.pre_scale || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad_t != 1 || a.pad_l != 1) return false;
+  if (a.Cin % BK != 0 || a.k_order != 1 || a.Ho != a.H || a.Wo != a.W) return false;
+  const int HW = a.H * a.W, WP = a.W + 2;
+  const int row_wraps = 62 / a.W + 1, img_wraps = a.N > 1 ? 62 / HW + 1 : 0;
+  const int e_bound = 63 + 2 * row_wraps + WP * img_wraps + 2 * WP + 4;
+  return e_bound <= PATCH_EMAX;
+}
+
 static bool pipe_applies(const ConvArgs& a, int64_t tiles, int KS, int64_t slots) {
   static const int sk_min_ks = getenv("DIF_SK_MIN_KS") ? atoi(getenv("DIF_SK_MIN_KS")) : 32;
   if (!a.use_pipe) return false;                                      // dif_net_set_option("pipe", 0)
@@ -966,6 +1146,9 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
   }
   if (pw && a.pre_scale) return launch_conv_pre<T, true, false, 1>(a, st);
   if (pw) return launch_conv_pre<T, false, false, 1>(a, st);
+  if constexpr (kDefaultTile) {
+    if (!use_dma && patch_applies(a)) return launch_conv_pre<T, false, false, 3>(a, st);
+  }
   if (a.pre_scale) return launch_conv_pre<T, true, false, 0>(a, st);
   if (use_dma) return launch_conv_pre<T, false, true, 0>(a, st);
   return launch_conv_pre<T, false, false, 0>(a, st);
@@ -974,9 +1157,8 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
 template <class T, bool PRE, bool DMA, int AM, bool BF3>
 static int launch_conv_pre(const ConvArgs& a, hipStream_t st) {
   auto kern = conv_igemm_kernel<T, PRE, DMA, AM, BF3>;
-  static const int lds_pad = getenv("DIF_CONV_LDS_PAD") ? atoi(getenv("DIF_CONV_LDS_PAD")) : 0;   // experiment: fewer blocks per CU
-  const int lds_bytes = (BF3 ? Bf3<T>::LDS_BYTES : T::LDS_BYTES) + lds_pad;
-  if (allow_dynamic_lds(kern, lds_bytes + 16384)) return -1;
+  constexpr int lds_bytes = BF3 ? Bf3<T>::LDS_BYTES : (AM == 3 ? PATCH_LDS_BYTES : T::LDS_BYTES);
+  if (allow_dynamic_lds(kern, lds_bytes)) return -1;
   const int64_t tiles = ((a.M + T::BM - 1) / T::BM) * (int64_t)((a.Cout + T::BN - 1) / T::BN);
   const int KS = a.Kpad / BK;
   const int64_t I = tiles * KS;
@@ -1009,10 +1191,10 @@ static int launch_conv_pre(const ConvArgs& a, hipStream_t st) {
   b.fd_kw = make_fastdiv(a.KW);
   b.fd_ks = make_fastdiv(KS);
   b.fd_taps = make_fastdiv(a.KH * a.KW);
+  b.fd_wp = make_fastdiv(a.W + 2);
+  b.fd_rpi = make_fastdiv(a.H + 1);
   if (a.k_order == 1 && a.Cin % BK != 0) return set_error("conv: channel-block-major K order needs Cin %% 32 == 0");
   b.fd_tiles_n = make_fastdiv((a.Cout + T::BN - 1) / T::BN);
-  static const int dbg = getenv("DIF_CONV_DBG") ? atoi(getenv("DIF_CONV_DBG")) : 0;   // development aid (ablations)
-  b.dbg = dbg;
   hipLaunchKernelGGL(kern, dim3((unsigned)P), dim3(T::NT), lds_bytes, st, b);
   DIF_HIP(hipGetLastError());
   return 0;

@@ -152,7 +152,7 @@ __device__ __forceinline__ void gemm_mainloop(ALoader& al, BLoader& bl, int kbeg
 // 128-VGPR budget of four waves per SIMD it spills, and loses 5-35 % on every layer class.)
 template <class T, class ALoader, class BLoader, class Tail>
 __device__ __forceinline__ void gemm_mainloop2(ALoader& al, BLoader& bl, int kbeg, int kend, float* lds,
-                                               f32x16 (&acc)[T::WM][T::WN], Tail&& tail, int dbg = 0) {
+                                               f32x16 (&acc)[T::WM][T::WN], Tail&& tail) {
   constexpr int WM = T::WM, WN = T::WN, BM = T::BM, BN = T::BN, NA = T::NA, NB = T::NB, RP = T::RP;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -188,13 +188,11 @@ __device__ __forceinline__ void gemm_mainloop2(ALoader& al, BLoader& bl, int kbe
                                                              acc[m][n], 0, 0, 0);
     }
   };
-  auto stage = [&](int buf, f32x4 (&ra)[NA], f32x4 (&rb)[NB], bool with_a = true) {
+  auto stage = [&](int buf, f32x4 (&ra)[NA], f32x4 (&rb)[NB]) {
     float* wa = lds + buf * BUF + st_off;
-    if (with_a) {
-      al.finish(ra);
+    al.finish(ra);
 #pragma unroll
-      for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(wa + i * RP * LDS_STRIDE) = ra[i];
-    }
+    for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(wa + i * RP * LDS_STRIDE) = ra[i];
 #pragma unroll
     for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(wa + OFFB + i * RP * LDS_STRIDE) = rb[i];
   };
@@ -207,17 +205,14 @@ __device__ __forceinline__ void gemm_mainloop2(ALoader& al, BLoader& bl, int kbe
   int ks = kbeg;
   for (; ks + 1 < kend; ++ks) {
     const int cur = (ks - kbeg) & 1;
-    // (ablation, DIF_CONV_DBG=32: the A operand is fetched and staged on one K-step in nine only -- results
-    // are wrong on purpose; it prices what a halo-resident A patch could save)
-    const bool with_a = !(dbg & 32) || ((ks + 1) % 9 == 0);
-    if (with_a) al.load(ks + 1, ra);
+    al.load(ks + 1, ra);
     bl.load(ks + 1, rb);
     // keep the prefetch where it is written: left alone, the scheduler sinks these loads below the
     // MFMAs, right in front of the LDS writes that consume them, and the loop stops overlapping
     // global-load latency with matrix work at all
     __builtin_amdgcn_sched_barrier(0);
     mfma_step(cur);
-    stage(cur ^ 1, ra, rb, with_a);
+    stage(cur ^ 1, ra, rb);
     __syncthreads();
   }
   tail();
@@ -331,7 +326,7 @@ struct Bf3WeightLoader {
 
 template <class T, class ALoader, class BLoader, class Tail>
 __device__ __forceinline__ void gemm_mainloop_bf3(ALoader& al, BLoader& bl, int kbeg, int kend, char* lds,
-                                                  f32x16 (&acc)[T::WM][T::WN], Tail&& tail, int dbg = 0) {
+                                                  f32x16 (&acc)[T::WM][T::WN], Tail&& tail) {
   constexpr int WM = T::WM, WN = T::WN, NA = T::NA, RP = T::RP;
   constexpr int OFFB = T::BM * BF3_ROWB;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -393,14 +388,12 @@ __device__ __forceinline__ void gemm_mainloop_bf3(ALoader& al, BLoader& bl, int 
   bl.load(kbeg, rb);
   int ks = kbeg;
   for (; ks + 1 < kend; ++ks) {
-    if (!(dbg & 16)) stage();
+    stage();
     __syncthreads();
-    if (!(dbg & 4)) {              // (ablation switches, DIF_CONV_DBG: 4 no global loads, 8 no MFMAs, 16 no staging)
-      al.load(ks + 1, ra);
-      bl.load(ks + 1, rb);
-    }
+    al.load(ks + 1, ra);
+    bl.load(ks + 1, rb);
     __builtin_amdgcn_sched_barrier(0);   // the prefetch stays above the MFMAs
-    if (!(dbg & 8)) mfma_step();
+    mfma_step();
     __syncthreads();   // every wave is done reading before the next K-step overwrites the image
   }
   // last K-step peeled: the caller's tail loads (the shortcut tile) hide behind its MFMAs, and their

@@ -85,6 +85,7 @@ struct ConvArgs {
   unsigned long long* trace;
   // launch-invariant divisors (filled by conv_run)
   FastDiv fd_howo, fd_wo, fd_cin, fd_kw, fd_ks, fd_tiles_n, fd_taps;
+  FastDiv fd_wp, fd_rpi;   // halo-patch path (conv.hip: PatchA): padded row width W + 2, padded rows per image H + 1
 };
 
 int conv_max_blocks();        // persistent blocks the kernel may use on this device
