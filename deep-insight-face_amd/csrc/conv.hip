@@ -325,16 +325,18 @@ struct ConvADmaLoader {
 // The next slice's patch is fetched into registers while taps 4..8 of the current one run, and written after a
 // barrier at the slice boundary (one extra barrier per nine K-steps).
 constexpr int PATCH_EMAX = 168;                       // entries a 64-pixel tile may need (host-checked bound)
-constexpr int PATCH_NPC = (PATCH_EMAX * 8 + 255) / 256;   // 16-byte chunks per thread per patch
 constexpr int PATCH_LDS_BYTES = PATCH_EMAX * 128 + 2 * 64 * 128;
 constexpr int PATCH_PF_TAP = 4;                       // tap of the current slice at which the next patch is requested
 
 __device__ __forceinline__ int patch_swz(int entry) { return (entry >> 1) & 7; }
 
+// T: the tile (BM output pixels, NT threads); EMAX: entries of the LDS patch
+template <class T, int EMAX>
 struct PatchA {
+  static constexpr int NPC = (EMAX * 8 + T::NT - 1) / T::NT;   // 16-byte chunks per thread per patch
   __amdgpu_buffer_rsrc_t rsrc;
-  uint32_t goff[PATCH_NPC];   // byte offset of this thread's chunk j inside channel slice 0, or OOB
-  int base;                   // entry of this lane's output pixel (row lane & 31 of the wave's 32 rows) for tap (0, 0)
+  uint32_t goff[NPC];   // byte offset of this thread's chunk j inside channel slice 0, or OOB
+  int base[T::WM];      // entry of this lane's output pixels (row lane & 31 of each of the wave's 32-row tiles), tap (0, 0)
   int WP;
   __device__ __forceinline__ PatchA(const ConvArgs& a, int m0) {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -345,54 +347,53 @@ struct PatchA {
     a.fd_howo.divmod(m0, n_first, r0);
     const int64_t img_elems = (int64_t)HW * a.Cin;
     const int64_t imgs_left = a.N - n_first;
-    int64_t span = (64 + HW - 1) / HW + 1;
+    int64_t span = (T::BM + HW - 1) / HW + 1;
     if (span > imgs_left) span = imgs_left;
     rsrc = make_rsrc(a.x + n_first * img_elems, (uint32_t)(span * img_elems * 4));
     int h0, w0;
     a.fd_wo.divmod(r0, h0, w0);
     const int p_first = (h0 + 1) * WP + (w0 + 1);      // P(m0), images counted from n_first
     const int origin = p_first - WP - 1;                // tap (0, 0) of the first pixel
-    // this lane's output pixel
-    {
-      const int wr = (tid >> 6) >> 1;                    // Tile<1,1,2,2>: wave row
-      int m = m0 + wr * 32 + (lane & 31);
+#pragma unroll
+    for (int mi = 0; mi < T::WM; ++mi) {
+      int m = m0 + (T::wave_row() * T::WM + mi) * 32 + (lane & 31);
       if (m >= a.M) m = m0;
       int n, r, h, w;
       a.fd_howo.divmod(m, n, r);
       a.fd_wo.divmod(r, h, w);
-      base = ((n - n_first) * RPI + h + 1) * WP + (w + 1) - p_first;
+      base[mi] = ((n - n_first) * RPI + h + 1) * WP + (w + 1) - p_first;
     }
-    // this thread's chunks of the patch
 #pragma unroll
-    for (int j = 0; j < PATCH_NPC; ++j) {
-      const int slot = tid + 256 * j;
+    for (int j = 0; j < NPC; ++j) {
+      const int slot = tid + T::NT * j;
       const int e = slot >> 3, q = slot & 7;
       const int c = origin + e;                          // padded linear coordinate
       int row, col, img, hp;
       a.fd_wp.divmod(c, row, col);
       a.fd_rpi.divmod(row, img, hp);
-      const bool ok = e < PATCH_EMAX && hp >= 1 && col >= 1 && col <= a.W && (n_first + img) < a.N;
+      const bool ok = e < EMAX && hp >= 1 && col >= 1 && col <= a.W && (n_first + img) < a.N;
       const int chunk = q ^ patch_swz(e);                // logical 4-channel chunk that lives in this physical slot
       goff[j] = ok ? (uint32_t)(((img * a.H + (hp - 1)) * a.W + (col - 1)) * a.Cin * 4 + chunk * 16) : OOB;
     }
   }
-  __device__ __forceinline__ void load(int cblk, f32x4 (&r)[PATCH_NPC]) const {
+  __device__ __forceinline__ void load(int cblk, f32x4 (&r)[NPC]) const {
 #pragma unroll
-    for (int j = 0; j < PATCH_NPC; ++j) r[j] = buf_load4(rsrc, goff[j] == OOB ? OOB : goff[j] + (uint32_t)cblk * 128u);
+    for (int j = 0; j < NPC; ++j) r[j] = buf_load4(rsrc, goff[j] == OOB ? OOB : goff[j] + (uint32_t)cblk * 128u);
   }
-  __device__ __forceinline__ void store(float* patch, const f32x4 (&r)[PATCH_NPC]) const {
+  // f32 patch: 128-byte entries, slot-linear (the swizzle is on the source side)
+  __device__ __forceinline__ void store(float* patch, const f32x4 (&r)[NPC]) const {
 #pragma unroll
-    for (int j = 0; j < PATCH_NPC; ++j) {
-      const int slot = threadIdx.x + 256 * j;
-      if (slot < PATCH_EMAX * 8) *reinterpret_cast<f32x4*>(patch + slot * 4) = r[j];
+    for (int j = 0; j < NPC; ++j) {
+      const int slot = threadIdx.x + T::NT * j;
+      if (slot < EMAX * 8) *reinterpret_cast<f32x4*>(patch + slot * 4) = r[j];
     }
   }
 };
 
 // Mainloop of the patch path: K-step ks = (channel slice ks / 9, tap ks % 9) -- the channel-block-major K order.
 // 64x64 tile, 4 waves (Tile<1,1,2,2>).  Ends on a barrier.
-template <class T, class BLoader, class Tail>
-__device__ __forceinline__ void gemm_mainloop_patch(const PatchA& pa, BLoader& bl, int kbeg, int kend, float* lds,
+template <class T, class PA, class BLoader, class Tail>
+__device__ __forceinline__ void gemm_mainloop_patch(const PA& pa, BLoader& bl, int kbeg, int kend, float* lds,
                                                     f32x16 (&acc)[1][1], Tail&& tail) {
   static_assert(T::BM == 64 && T::BN == 64 && T::NT == 256, "patch path: 64x64 tile");
   constexpr int NB = T::NB, RP = T::RP;
@@ -406,7 +407,7 @@ __device__ __forceinline__ void gemm_mainloop_patch(const PatchA& pa, BLoader& b
   const int rb_swz = patch_swz(rb_row);
   const float* pb0 = bimg + rb_row * 32;
 
-  f32x4 pr[PATCH_NPC], rb[NB];
+  f32x4 pr[PA::NPC], rb[NB];
   int cb = kbeg / 9, tap = kbeg - cb * 9;
   pa.load(cb, pr);
   bl.load(kbeg, rb);
@@ -423,7 +424,7 @@ __device__ __forceinline__ void gemm_mainloop_patch(const PatchA& pa, BLoader& b
   bool pf_issued = false;
   auto mfma_step = [&](int cur) {
     const int kh = tap >= 6 ? 2 : (tap >= 3 ? 1 : 0);
-    const int e = pa.base + kh * pa.WP + (tap - 3 * kh);
+    const int e = pa.base[0] + kh * pa.WP + (tap - 3 * kh);
     const int sa = patch_swz(e);
     const float* pae = patch + e * 32;
     const float* pbe = pb0 + cur * (64 * 32);
@@ -651,7 +652,7 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const 
     using ALoadReg = typename std::conditional<AM == 1, ConvPwLoader<T::NA, T::RP, PRE>,
                                                ConvALoader<T::NA, T::RP, PRE, AM == 2 ? 2 : 0>>::type;
     using ALoadGather = typename std::conditional<DMA, ConvADmaLoader<T::NA, T::RP>, ALoadReg>::type;
-    using ALoad = typename std::conditional<AM == 3, PatchA, ALoadGather>::type;     // AM 3: halo-resident patch
+    using ALoad = typename std::conditional<AM == 3, PatchA<T, PATCH_EMAX>, ALoadGather>::type;   // AM 3: halo-resident patch
     using BLoadF32 = typename std::conditional<DMA, DmaRowLoader<T::NB, T::RP>, RowLoader<T::NB, T::RP>>::type;
     using BLoad = typename std::conditional<BF3, Bf3WeightLoader<T>, BLoadF32>::type;
     ALoad al(a, m0);
@@ -1095,13 +1096,14 @@ static int launch_conv_pipe(const ConvArgs& a, hipStream_t st) {
 // 64-pixel tile's halo patch bounded by PATCH_EMAX entries (row wraps add 2 entries each, an image boundary adds
 // one padded row).  IResNet's 28x28, 14x14 and 7x7 stages qualify; 56x56 and up keep the per-K-step gather.
 static bool patch_applies(const ConvArgs& a) {
+  constexpr int BM = 64, emax = PATCH_EMAX;
   static const bool on = !(getenv("DIF_NO_PATCH") && atoi(getenv("DIF_NO_PATCH")));
   if (!on || a.pre_scale || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad_t != 1 || a.pad_l != 1) return false;
   if (a.Cin % BK != 0 || a.k_order != 1 || a.Ho != a.H || a.Wo != a.W) return false;
   const int HW = a.H * a.W, WP = a.W + 2;
-  const int row_wraps = 62 / a.W + 1, img_wraps = a.N > 1 ? 62 / HW + 1 : 0;
-  const int e_bound = 63 + 2 * row_wraps + WP * img_wraps + 2 * WP + 4;
-  return e_bound <= PATCH_EMAX;
+  const int row_wraps = (BM - 2) / a.W + 1, img_wraps = a.N > 1 ? (BM - 2) / HW + 1 : 0;
+  const int e_bound = (BM - 1) + 2 * row_wraps + WP * img_wraps + 2 * WP + 4;
+  return e_bound <= emax;
 }
 
 static bool pipe_applies(const ConvArgs& a, int64_t tiles, int KS, int64_t slots) {

@@ -310,8 +310,9 @@ __global__ __launch_bounds__(256) void gdc_tail_kernel(const float* __restrict__
                                                        const float* __restrict__ wpw, const float* __restrict__ wd,
                                                        float* __restrict__ y, int N, int HW, int E, float eps) {
   constexpr int C = 512;
-  __shared__ float a[2][C];
-  __shared__ float b[2][1024];
+  __shared__ float a[2][C];            // depthwise + BN output of the block's two images
+  __shared__ float b[2][1024];         // 1x1 convolution output
+  __shared__ float part[2][2][1024];   // [K half][image][j]: partial sums of the two matrix-vector products
   __shared__ float red[2][4];
   const int tid = threadIdx.x;
   const int64_t n0 = (int64_t)blockIdx.x * 2;
@@ -330,35 +331,44 @@ __global__ __launch_bounds__(256) void gdc_tail_kernel(const float* __restrict__
     a[1][c] = fmaf(s1, sc, sh);
   }
   __syncthreads();
-  for (int j = tid; j < E; j += 256) {
-    float s0 = 0.f, s1 = 0.f;
-#pragma unroll 8
-    for (int c = 0; c < C; ++c) {
-      const float w = wpw[(int64_t)c * E + j];
-      s0 = fmaf(a[0][c], w, s0);
-      s1 = fmaf(a[1][c], w, s1);
+  // y[j] = sum_k v[k] * W[k][j] for both images: a thread owns four adjacent outputs (one 16-byte weight load per k)
+  // and one half of the k range; sixteen loads in flight per thread keep the L2 round trip covered
+  const int half = tid >> 7, jq = tid & 127;
+  auto gemv = [&](const float* W, int K, const float* v0, const float* v1) {
+    const int k0 = half * (K / 2), k1 = k0 + K / 2;
+    for (int j = 4 * jq; j < E; j += 512) {
+      f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 16
+      for (int k = k0; k < k1; ++k) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(W + (int64_t)k * E + j);
+        const float u0 = v0[k], u1 = v1[k];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          s0[q] = fmaf(u0, w[q], s0[q]);
+          s1[q] = fmaf(u1, w[q], s1[q]);
+        }
+      }
+      *reinterpret_cast<f32x4*>(&part[half][0][j]) = s0;
+      *reinterpret_cast<f32x4*>(&part[half][1][j]) = s1;
     }
-    b[0][j] = s0;
-    b[1][j] = s1;
+  };
+  gemv(wpw, C, a[0], a[1]);
+  __syncthreads();
+  for (int j = tid; j < E; j += 256) {
+    b[0][j] = part[0][0][j] + part[1][0][j];
+    b[1][j] = part[0][1][j] + part[1][1][j];
   }
+  __syncthreads();
+  gemv(wd, E, b[0], b[1]);
   __syncthreads();
   float o0[4], o1[4], ss0 = 0.f, ss1 = 0.f;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int j = tid + 256 * q;
-    float s0 = 0.f, s1 = 0.f;
-    if (j < E) {
-#pragma unroll 8
-      for (int i = 0; i < E; ++i) {
-        const float w = wd[(int64_t)i * E + j];
-        s0 = fmaf(b[0][i], w, s0);
-        s1 = fmaf(b[1][i], w, s1);
-      }
-    }
-    o0[q] = s0;
-    o1[q] = s1;
-    ss0 = fmaf(s0, s0, ss0);
-    ss1 = fmaf(s1, s1, ss1);
+    o0[q] = j < E ? part[0][0][j] + part[1][0][j] : 0.f;
+    o1[q] = j < E ? part[0][1][j] + part[1][1][j] : 0.f;
+    ss0 = fmaf(o0[q], o0[q], ss0);
+    ss1 = fmaf(o1[q], o1[q], ss1);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -385,7 +395,7 @@ __global__ __launch_bounds__(256) void gdc_tail_kernel(const float* __restrict__
 int gdc_tail_run(const float* x, const float* w_dw, const float* scale, const float* shift, const float* w_pw,
                  const float* w_dense, float* y, int N, int HW, int E, float eps, hipStream_t st) {
   if (N == 0) return 0;
-  if (E > 1024) return set_error("gdc_tail: emd %d > 1024", E);
+  if (E > 1024 || E % 8 != 0) return set_error("gdc_tail: emd %d must be a multiple of 8, at most 1024", E);
   hipLaunchKernelGGL(gdc_tail_kernel, dim3((unsigned)((N + 1) / 2)), dim3(256), 0, st, x, w_dw, scale, shift, w_pw, w_dense,
                      y, N, HW, E, eps);
   DIF_HIP(hipGetLastError());

@@ -261,7 +261,7 @@ int Net::build_heads(int feat) {
     // triplet.py:129-130  DepthwiseConv2D(kernel = map size) -> BN
     if (fd.H != fd.W) return set_error("GDC head needs a square feature map (got %dx%d)", fd.H, fd.W);
     static const bool fuse_tail = !(getenv("DIF_NO_TAIL_FUSION") && atoi(getenv("DIF_NO_TAIL_FUSION")));
-    if (fuse_tail && emd <= 1024) {
+    if (fuse_tail && emd <= 1024 && emd % 8 == 0) {
       // triplet.py:129-138 in ONE launch: depthwise over the whole map + BN -> Conv1x1(emd) ->
       // [Dropout = identity] -> Flatten -> Dense(emd) -> l2_normalize.  0.5 MMAC per image: latency, not MFMA work.
       Op g;
