@@ -213,6 +213,52 @@ def cpu_baseline(arch, head, gallery_rows, budget_s=12.0):
     }
 
 
+def cpu_baseline_frames(gallery_rows, det_params, n_frames=4):
+    """configs[4] on the host cores: PIL letterbox (the reference's own call, detector/yolov3.py:108-119) ->
+    YOLOv3-face on torch-CPU ops -> box decode + NMS (oracle/detector.py) -> area-resampled crop (oracle/
+    imageops.py) -> ResNet-50V2 on torch-CPU ops -> reference-formula match.  A handful of frames: the detector
+    alone is 65 GFLOP per frame."""
+    sys.path.insert(0, ROOT)
+    from oracle import detector as odet
+    from oracle import distance as od
+    from oracle import imageops as oi
+    from oracle import nets, torch_nets
+    from deep_insight_face.networks.weights import synth_params
+    cores, quota = usable_cores()
+    torch.set_num_threads(cores)
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(cores)
+    except Exception:
+        pass
+    p = synth_params(nets.model_spec('resnet', 512, 112, 'v2'))
+    rng = np.random.default_rng(1234)
+    frames = rng.integers(0, 256, (n_frames, 480, 640, 3), dtype=np.uint8)
+    gal = rng.standard_normal((gallery_rows, 512)).astype(np.float32)
+    gal /= np.linalg.norm(gal, axis=1, keepdims=True)
+    anchors = np.array([10, 13, 16, 30, 33, 23, 30, 61, 62, 45, 59, 119, 116, 90, 156, 198, 373, 326], dtype=np.float32).reshape(-1, 2)
+
+    def run(fr):
+        lb = np.stack([oi.letterbox(f, 416) for f in fr]).astype(np.float32) / np.float32(255)
+        maps = torch_nets.yolov3(lb, det_params)
+        crops = []
+        for i, f in enumerate(fr):
+            b, sc, _ = odet.get_yolo_output([m[i:i + 1] for m in maps], anchors, 1, (480, 640), 1, 0.4, 0.5)
+            box = [b[0][1], b[0][0], b[0][3], b[0][2]] if len(b) else [0, 0, 640, 480]
+            crops.append(oi.crop_resize(f, box, 8, 112))
+        e = torch_nets.embed(np.stack(crops).astype(np.float32) / np.float32(255), p, 'resnet', 'v2')
+        od.match(e, gal, 1)
+
+    run(frames[:1])
+    t0 = time.perf_counter()
+    run(frames)
+    dt = time.perf_counter() - t0
+    return {'value': n_frames / dt, 'unit': 'frames/s', 'cores': cores, 'kind': 'port', 'cpu_model': cpu_model_string(),
+            'host_hw_threads': os.cpu_count(), 'cgroup_cpu_quota': quota,
+            'sample': '%d frames 640x480: PIL letterbox + YOLOv3-face and ResNet-50V2 on torch-CPU ops (%d threads) + oracle '
+                      'decode/NMS/crop + reference-formula match vs %d rows, %.2fs' % (n_frames, cores, gallery_rows, dt)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -426,8 +472,9 @@ def main():
                                        'faces_per_s_embed_only': 256 / (b256_ms * 1e-3),
                                        'traffic': measured_traffic('r100', 256),
                                        'note': 'north_star target configuration: IResNet-100 forward at batch 256'}
-        if world == 1 and not args.no_cpu_baseline and pipe is None:
-            out['cpu_baseline'] = cpu_baseline(arch, head, gallery_rows)
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = (cpu_baseline(arch, head, gallery_rows) if pipe is None else
+                                   cpu_baseline_frames(gallery_rows, dp))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

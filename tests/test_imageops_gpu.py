@@ -51,13 +51,16 @@ def test_crop_resize_matches_oracle():
             assert (diff == 0).mean() > 0.98
 
 
-def test_frame_pipeline_end_to_end():
-    """Device pipeline == the same stages run one by one through the host-visible API."""
+@pytest.mark.parametrize('nframes,h,w', [(4, 240, 320), (96, 480, 640)])
+def test_frame_pipeline_end_to_end(nframes, h, w):
+    """Device pipeline == the same stages run one by one through the host-visible API; at 4 small frames and
+    at 96 frames of BASELINE configs[4]'s 640x480 (the detector then runs in chunks of its max_batch = 64,
+    the embedder splits its batch over two lanes...)."""
     from deep_insight_face import oneshot
     from deep_insight_face.detector import run as drun, yolov3 as yolo
     from deep_insight_face.networks.triplet import bottleneck_network
     from deep_insight_face.networks.weights import synth_params
-    det = drun.yolo_v3_face(max_batch=4)
+    det = drun.yolo_v3_face(max_batch=min(nframes, 64))
     p = synth_params(det.param_spec(), seed=11)
     for k in p:                                   # keep exp() in the box decode finite
         if k in ('conv_58/kernel', 'conv_66/kernel', 'conv_74/kernel'):
@@ -68,21 +71,21 @@ def test_frame_pipeline_end_to_end():
             p[k][5::6] = 2.0
     det.set_weights(p)
     det.set_input_transform(scale=1 / 255.)
-    emb = bottleneck_network('resnet', emd_size=512, input_shape=(112, 112, 3), max_batch=4)('v2')
+    emb = bottleneck_network('resnet', emd_size=512, input_shape=(112, 112, 3), max_batch=nframes)('v2')
     emb.init_synthetic(3)
     emb.set_input_transform(scale=1 / 255.)
     rng = np.random.default_rng(0)
     gal = rng.standard_normal((1000, 512)).astype(np.float32)
     pipe = drun.FramePipeline(det, emb, oneshot.Gallery(gal), margin=8, score=0.4)
-    frames = _frames(4, 240, 320, 9)
+    frames = _frames(nframes, h, w, 9)
     boxes, scores, e, idx, dist = pipe(frames)
     boxes, scores = boxes.cpu().numpy(), scores.cpu().numpy()
     assert np.isfinite(boxes).all() and (scores >= 0.4).all()
     # stage by stage
     lb = yolo.letterbox_batch(frames, 416)
     maps = det.embed(lb)
-    for i in range(4):
-        b, s, c = yolo.get_yolo_output([m[i:i + 1] for m in maps], drun.ANCHORS.reshape(-1, 2), 1, (240, 320),
+    for i in range(0, nframes, max(1, nframes // 8)):
+        b, s, c = yolo.get_yolo_output([m[i:i + 1] for m in maps], drun.ANCHORS.reshape(-1, 2), 1, (h, w),
                                        max_boxes=1, score_threshold=0.4)
         top, left, bottom, right = b[0]
         np.testing.assert_allclose(boxes[i], [left, top, right, bottom], rtol=0, atol=0)

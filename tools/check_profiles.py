@@ -1,8 +1,7 @@
-"""Copies the latest rocprofv3 summaries from gpurun_out/ into profiles/ and prints the
-cross-check the bench line's `roofline` rests on: per forward, the sum of the conv kernel
-durations in the kernel-trace stats vs the HIP-event forward time reported by bench.py."""
+"""Copies the round-2 rocprofv3 summaries from gpurun_out/r02/ into profiles/ and prints the cross-checks
+the bench line's `roofline` rests on: per forward, the sum of the conv kernel durations in the kernel-trace stats
+(one lane: no overlap) vs the HIP-event forward time reported by bench.py, and the frac recomputed from them."""
 import csv
-import glob
 import json
 import os
 import shutil
@@ -10,52 +9,97 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, 'gpurun_out')
+OUT = os.path.join(ROOT, 'gpurun_out', 'r02')
 PROF = os.path.join(ROOT, 'profiles')
-ROUND = 'r01'
+R = 'r02'
+PEAK = 157.3
 
 
-def latest(pattern):
-    files = sorted(glob.glob(os.path.join(OUT, pattern)), key=os.path.getmtime)
-    return files[-1] if files else None
+def jl(path):
+    with open(path) as fh:
+        for line in fh:
+            if line.startswith('{'):
+                return json.loads(line)
+    raise RuntimeError('no JSON line in ' + path)
+
+
+def conv_ms(stats_csv):
+    ns = calls = 0
+    for r in csv.DictReader(open(stats_csv)):
+        if 'conv_igemm_kernel' in r['Name'] or 'conv_pipe_kernel' in r['Name']:
+            ns += float(r['TotalDurationNs'])
+            calls += int(r['Calls'])
+    return ns / 1e6, calls
+
+
+def cp(src, dst):
+    shutil.copy(os.path.join(OUT, src), os.path.join(PROF, dst))
+
+
+def tool(name, args, dst):
+    with open(os.path.join(PROF, dst), 'w') as fh:
+        subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', name)] + args, stdout=fh)
 
 
 def main():
     lines = []
-    for w, forwards_ks in (('r50', 14), ('r100', 14)):
-        ks = latest('ks1_%s/*/*_kernel_stats.csv' % w)          # single-lane run: durations do not overlap
-        ks2 = latest('ks_%s/*/*_kernel_stats.csv' % w)          # default two-lane run
-        shutil.copy(ks2, os.path.join(PROF, '%s_%s_b256_kernel_stats_2lanes.csv' % (ROUND, w)))
-        shutil.copy(os.path.join(OUT, 'bench1_%s.json' % w), os.path.join(PROF, '%s_%s_b256_bench_1lane.json' % (ROUND, w)))
-        bench1 = json.load(open(os.path.join(OUT, 'bench1_%s.json' % w)))
-        pf = latest('pf_%s/*/*_counter_collection.csv' % w)
-        pw = latest('pw_%s/*/*_counter_collection.csv' % w)
-        shutil.copy(ks, os.path.join(PROF, '%s_%s_b256_kernel_stats.csv' % (ROUND, w)))
-        shutil.copy(os.path.join(OUT, 'layers_%s.txt' % w), os.path.join(PROF, '%s_%s_b256_layers.txt' % (ROUND, w)))
-        shutil.copy(os.path.join(OUT, 'bench_%s.json' % w), os.path.join(PROF, '%s_%s_b256_bench.json' % (ROUND, w)))
-        pm = latest('pm_%s/*/*_counter_collection.csv' % w)
-        if pm:
-            with open(os.path.join(PROF, '%s_%s_b256_mfma_util.json' % (ROUND, w)), 'w') as fh:
-                subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', 'pmc_mfma.py'), pm], stdout=fh)
-        with open(os.path.join(PROF, '%s_%s_b256_hbm_traffic.json' % (ROUND, w)), 'w') as fh:
-            subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', 'pmc_traffic.py'), pf, pw, '5'], stdout=fh)
-        conv_ns, conv_calls = 0.0, 0
-        for r in csv.DictReader(open(ks)):
-            if 'conv_igemm_kernel' in r['Name'] or 'conv_pipe_kernel' in r['Name']:
-                conv_ns += float(r['TotalDurationNs'])
-                conv_calls += int(r['Calls'])
-        bench = json.load(open(os.path.join(OUT, 'bench_%s.json' % w)))
-        traffic = json.load(open(os.path.join(PROF, '%s_%s_b256_hbm_traffic.json' % (ROUND, w))))['total']
-        lines.append('%-4s ONE lane (DIF_STREAMS=1): %d conv launches/forward, sum of conv kernel durations %.3f ms/forward '
-                     '(rocprofv3 kernel-trace) vs HIP-event forward %.3f ms (%.1f TFLOP/s, frac %.3f)\n'
-                     '     default executor: HIP-event forward %.3f ms, %.1f TFLOP/s, frac %.3f, %.0f faces/s incl. match | '
-                     'fabric traffic %.1f GB/forward'
-                     % (w, conv_calls // forwards_ks, conv_ns / forwards_ks / 1e6,
-                        bench1['roofline']['forward_ms_hip_events'], bench1['roofline']['achieved'], bench1['roofline']['frac'],
-                        bench['roofline']['forward_ms_hip_events'], bench['roofline']['achieved'], bench['roofline']['frac'],
-                        bench['value'], traffic['conv_hbm_bytes_per_forward'] / 1e9))
+    cp('ks_default/p_kernel_stats.csv', R + '_default_kernel_stats.csv')
+    cp('ks_default.json', R + '_default_bench_profiled.json')
+    cp('ks_default_1lane/p_kernel_stats.csv', R + '_default_1lane_kernel_stats.csv')
+    cp('ks_default_1lane.json', R + '_default_1lane_bench_profiled.json')
+    cp('ks_r50_1lane/p_kernel_stats.csv', R + '_r50_1lane_kernel_stats.csv')
+    for w in ('default', 'default_1lane', 'r100', 'r50', 'r50_1lane', 'r100_arc', 'r100_1m_bf16x3', 'frames'):
+        cp('bench_%s.json' % w, '%s_%s_bench.json' % (R, w))
+    for src, dst in (('layers_r100.txt', 'r100_b256_layers.txt'), ('layers_r50.txt', 'r50_b256_layers.txt'),
+                     ('layers_r100_bf16x3.txt', 'r100_b256_bf16x3_layers.txt'), ('layers_yolov3.txt', 'yolov3_b64_layers.txt'),
+                     ('latency.txt', 'latency.txt')):
+        cp(src, R + '_' + src.replace(src, dst))
+    # forwards per profiled run: steps + warmup + 1 per-layer profile (+ 6 batch-256 forwards in the default workload)
+    tool('pmc_traffic.py', [os.path.join(OUT, 'pf_default/p_counter_collection.csv'),
+                            os.path.join(OUT, 'pw_default/p_counter_collection.csv'), '8'], R + '_r100_1m_b512_hbm_traffic.json')   # 5 forwards of 512 + 6 of 256
+    tool('pmc_traffic.py', [os.path.join(OUT, 'pf_r100/p_counter_collection.csv'),
+                            os.path.join(OUT, 'pw_r100/p_counter_collection.csv'), '5'], R + '_r100_b256_hbm_traffic.json')
+    tool('pmc_traffic.py', [os.path.join(OUT, 'pf_r50/p_counter_collection.csv'),
+                            os.path.join(OUT, 'pw_r50/p_counter_collection.csv'), '5'], R + '_r50_b256_hbm_traffic.json')
+    tool('pmc_mfma.py', [os.path.join(OUT, 'pm_default/p_counter_collection.csv')], R + '_r100_1m_mfma_util.json')
+
+    # cross-check 1: default workload, ONE lane.  forwards of batch 512 in the profiled run: 20 + 5 + 1 profile
+    # = 26, plus 1 + max(5, min(20, 20)) = 21 forwards of batch 256 (= 10.5 forwards of 512 in conv time)
+    one = jl(os.path.join(OUT, 'ks_default_1lane.json'))
+    ms, calls = conv_ms(os.path.join(OUT, 'ks_default_1lane/p_kernel_stats.csv'))
+    fw = 26 + 21 * 0.5
+    per_fw = ms / fw
+    flops = one['roofline']['algorithmic_flops_per_forward']
+    lines.append('default workload (IResNet-100, 512 faces, 1M gallery), ONE lane, under rocprofv3: %d conv launches, '
+                 'sum of conv kernel durations %.2f ms = %.2f ms per batch-512 forward (kernel-trace stats) vs HIP-event forward '
+                 '%.2f ms in the same run; frac from the stats %.4f vs bench %.4f'
+                 % (calls, ms, per_fw, one['roofline']['forward_ms_hip_events'], flops / (per_fw * 1e-3) / 1e12 / PEAK,
+                    one['roofline']['frac']))
+    d = jl(os.path.join(OUT, 'bench_default.json'))
+    dp = jl(os.path.join(OUT, 'ks_default.json'))
+    lines.append('default workload, default executor (two lanes): un-profiled %.0f faces/s, forward %.2f ms, frac %.4f (b256: '
+                 '%.2f ms, frac %.4f), match %.2f ms; the same command under rocprofv3 --kernel-trace: %.0f faces/s, frac %.4f'
+                 % (d['value'], d['roofline']['forward_ms_hip_events'], d['roofline']['frac'],
+                    d['roofline']['b256']['forward_ms_hip_events'], d['roofline']['b256']['frac'], d['phases_ms']['match'],
+                    dp['value'], dp['roofline']['frac']))
+    # cross-check 2: ResNet-50V2 one lane: 10 + 3 + 1 forwards
+    r50 = jl(os.path.join(OUT, 'bench_r50_1lane.json'))
+    ms, calls = conv_ms(os.path.join(OUT, 'ks_r50_1lane/p_kernel_stats.csv'))
+    lines.append('r50 (configs[1]), ONE lane: %d conv launches per forward, %.3f ms of conv kernels per forward (stats) vs HIP-event '
+                 'forward %.3f ms (un-profiled run), frac %.4f' % (calls // 14, ms / 14, r50['roofline']['forward_ms_hip_events'],
+                                                                  r50['roofline']['frac']))
+    for w in ('r100', 'r50', 'r100_arc', 'r100_1m_bf16x3', 'frames'):
+        b = jl(os.path.join(OUT, 'bench_%s.json' % w))
+        lines.append('%-16s %8.0f %s  step %.2f ms  phases %s  frac(f32 peak) %.4f'
+                     % (w, b['value'], b['unit'], b['ms_per_step'], json.dumps(b['phases_ms']), b['roofline']['frac']))
+    for w, f in (('r100_1m b512', R + '_r100_1m_b512_hbm_traffic.json'), ('r100 b256', R + '_r100_b256_hbm_traffic.json'),
+                 ('r50 b256', R + '_r50_b256_hbm_traffic.json')):
+        t = json.load(open(os.path.join(PROF, f)))['total']
+        lines.append('fabric traffic %-13s %.2f GB per forward (read %.2f + write %.2f)'
+                     % (w, t['conv_hbm_bytes_per_forward'] / 1e9, t['conv_read_bytes_per_forward'] / 1e9,
+                        t['conv_write_bytes_per_forward'] / 1e9))
     print('\n'.join(lines))
-    with open(os.path.join(PROF, '%s_summary.txt' % ROUND), 'w') as fh:
+    with open(os.path.join(PROF, R + '_summary.txt'), 'w') as fh:
         fh.write('\n'.join(lines) + '\n')
 
 

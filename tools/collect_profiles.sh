@@ -1,26 +1,39 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): rocprofv3 kernel-trace stats + separate PMC passes of the
-# exact bench.py commands, plus the un-profiled bench lines and per-layer tables.
-# Outputs land in gpurun_out/; tools/check_profiles.py copies the summaries into profiles/.
+# Round-2 evidence run, on the GPU box (via gpurun): rocprofv3 kernel-trace stats of the EXACT driver command
+# (python3 bench.py --gpus 1 --steps 20 --warmup 5), separate PMC passes (never combined with tracing), the
+# un-profiled bench lines of every workload, per-layer tables and the small-batch latency table.
+# Outputs land in gpurun_out/r02/; tools/check_profiles.py copies the summaries into profiles/.
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-# Per-kernel durations are taken with ONE lane (DIF_STREAMS=1): with two lanes kernels of the two
-# streams overlap and the sum of per-kernel durations double-counts the wall clock.
-for w in r50 r100; do
-  export DIF_STREAMS=1
-  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ks1_$w -- python3 bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/ks1_$w.log 2>&1
-  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pm_$w -- python3 bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/pm_$w.log 2>&1
-  unset DIF_STREAMS
-  export DIF_STREAMS=2     # the "two lanes" files (IResNet-100's default; ResNet50V2 defaults to one lane)
-  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ks_$w -- python3 bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/ks_$w.log 2>&1
-  unset DIF_STREAMS
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pf_$w -- python3 bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/pf_$w.log 2>&1
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pw_$w -- python3 bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/pw_$w.log 2>&1
-done
-DIF_STREAMS=1 python3 bench.py --no-cpu-baseline > gpurun_out/bench1_r50.json 2>/dev/null
-DIF_STREAMS=1 python3 bench.py --workload r100 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench1_r100.json 2>/dev/null
-python3 bench.py > gpurun_out/bench_r50.json 2>/dev/null
-python3 bench.py --workload r100 --steps 10 --warmup 3 > gpurun_out/bench_r100.json 2>/dev/null
-python3 tools/layer_profile.py resnet 256 > gpurun_out/layers_r50.txt
-python3 tools/layer_profile.py iresnet100 256 > gpurun_out/layers_r100.txt
-echo done
+O=gpurun_out/r02
+mkdir -p $O
+prof() { local tag=$1; shift; rocprofv3 "$@" --output-format csv -d $O/$tag -o p -- python3 bench.py --gpus 1 ${ARGS} > $O/$tag.json 2> $O/$tag.err; }
+# 1. the driver's command, default executor (two lanes: kernel durations of the two streams overlap)
+ARGS="--steps 20 --warmup 5" prof ks_default --kernel-trace --stats &&
+# 2. the same workload on ONE lane: kernels run back to back, so per-kernel durations add up to the forward
+DIF_STREAMS=1 ARGS="--steps 20 --warmup 5 --no-cpu-baseline" prof ks_default_1lane --kernel-trace --stats &&
+# 3. counters, each in its own pass
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline" prof pf_default --pmc FETCH_SIZE &&
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline" prof pw_default --pmc WRITE_SIZE &&
+DIF_STREAMS=1 ARGS="--steps 3 --warmup 1 --no-cpu-baseline" prof pm_default --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE &&
+ARGS="--workload r100 --steps 3 --warmup 1 --no-cpu-baseline" prof pf_r100 --pmc FETCH_SIZE &&
+ARGS="--workload r100 --steps 3 --warmup 1 --no-cpu-baseline" prof pw_r100 --pmc WRITE_SIZE &&
+DIF_STREAMS=1 ARGS="--workload r50 --steps 10 --warmup 3 --no-cpu-baseline" prof ks_r50_1lane --kernel-trace --stats &&
+ARGS="--workload r50 --steps 3 --warmup 1 --no-cpu-baseline" prof pf_r50 --pmc FETCH_SIZE &&
+ARGS="--workload r50 --steps 3 --warmup 1 --no-cpu-baseline" prof pw_r50 --pmc WRITE_SIZE &&
+# 4. un-profiled bench lines
+python3 bench.py > $O/bench_default.json 2> $O/bench_default.err &&
+DIF_STREAMS=1 python3 bench.py --no-cpu-baseline > $O/bench_default_1lane.json 2>/dev/null &&
+python3 bench.py --workload r100 > $O/bench_r100.json 2>/dev/null &&
+python3 bench.py --workload r50 > $O/bench_r50.json 2>/dev/null &&
+DIF_STREAMS=1 python3 bench.py --workload r50 --no-cpu-baseline > $O/bench_r50_1lane.json 2>/dev/null &&
+python3 bench.py --workload r100_arc --no-cpu-baseline > $O/bench_r100_arc.json 2>/dev/null &&
+python3 bench.py --workload r100_1m_bf16x3 --no-cpu-baseline > $O/bench_r100_1m_bf16x3.json 2>/dev/null &&
+python3 bench.py --workload frames --steps 3 --warmup 1 > $O/bench_frames.json 2>/dev/null &&
+# 5. per-layer tables, latency
+python3 tools/layer_profile.py iresnet100 256 > $O/layers_r100.txt 2>&1 &&
+python3 tools/layer_profile.py resnet 256 > $O/layers_r50.txt 2>&1 &&
+python3 tools/layer_profile.py iresnet100 256 bf16x3 > $O/layers_r100_bf16x3.txt 2>&1 &&
+python3 tools/layer_profile.py yolov3 64 > $O/layers_yolov3.txt 2>&1 &&
+python3 tools/latency.py > $O/latency.txt 2>&1
+echo "collect rc=$?"

@@ -27,7 +27,7 @@ def load(path, counter):
 def main():
     fetch, nf = load(sys.argv[1], 'FETCH_SIZE')
     write, _ = load(sys.argv[2], 'WRITE_SIZE')
-    forwards = int(sys.argv[3])
+    forwards = float(sys.argv[3])
     out = {}
     for k in sorted(set(fetch) | set(write)):
         out[k] = {'launches_per_forward': nf.get(k, 0) / forwards,
