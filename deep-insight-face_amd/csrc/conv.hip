@@ -324,7 +324,7 @@ struct ConvADmaLoader {
 // PATCH_EMAX * 128 + 2 * 64 * 128 = 37.9 KB of LDS: four blocks per CU, as before.
 // The next slice's patch is fetched into registers while taps 4..8 of the current one run, and written after a
 // barrier at the slice boundary (one extra barrier per nine K-steps).
-constexpr int PATCH_EMAX = 168;                       // entries a 64-pixel tile may need (host-checked bound)
+constexpr int PATCH_EMAX = 128;                       // entries a 64-pixel tile may need (host-checked bound): maps up to 14 wide
 constexpr int PATCH_LDS_BYTES = PATCH_EMAX * 128 + 2 * 64 * 128;
 constexpr int PATCH_PF_TAP = 4;                       // tap of the current slice at which the next patch is requested
 
@@ -663,7 +663,8 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const 
         return BLoad(a.w + (int64_t)n0 * a.Kpad, (int64_t)a.Cout - n0, a.Kpad);
     }();
     // this block computes the whole tile: fetch the shortcut tile behind the last K-step
-    const bool whole = !DMA && kb == 0 && ke == KS;
+    // (not on the patch path: its prefetch registers leave no room, the shortcut tile would only be spilled)
+    const bool whole = !DMA && AM != 3 && kb == 0 && ke == KS;
     EpiRes<T> er;
     auto run = [&](int k0, int k1, bool prefetch_res) {
       if constexpr (BF3)

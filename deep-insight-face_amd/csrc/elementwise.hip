@@ -300,6 +300,119 @@ int dwfull_run(const float* x, const float* w, const float* scale, const float* 
   return 0;
 }
 
+// ---------------------------------------------------------------- 3-channel 3x3 stem, direct
+// The first layer of YOLOv3-face (Conv3x3(32) at 416x416; the same shape as IResNet's conv1, which measured no
+// faster this way and stays on the MFMA path): 27 inputs per output value.  As an implicit GEMM its K (36, padded
+// to 64) wastes 44 % of the MFMA work and the layer is bound by its output rows anyway.  Direct form: 16 pixels x 4 channel
+// groups per wave, the 27 x Cout weights in LDS (broadcast reads), 27 x Cout/4 fma per thread, the same
+// epilogue as the convolution kernels: y = act(acc * scale + shift), optional y2 = act2(y * scale2 + shift2).
+template <int COUT>
+__global__ __launch_bounds__(256, 4) void stem3x3_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ scale, const float* __restrict__ shift,
+                                                      const float* __restrict__ alpha, const float* __restrict__ scale2,
+                                                      const float* __restrict__ shift2, const float* __restrict__ alpha2,
+                                                      float* __restrict__ y, float* __restrict__ y2, int N, int H, int W,
+                                                      int act, int act2) {
+  constexpr int CG = COUT / 4;                    // output channels per thread
+  __shared__ __attribute__((aligned(16))) float ws[27 * COUT];   // Keras HWIO as it is: [kh][kw][ci < 3][co]
+  const int tid = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) float ep[6][COUT];     // epilogue vectors (defaults where absent)
+  for (int i = tid; i < 27 * COUT; i += 256) ws[i] = w[i];
+  for (int c = tid; c < COUT; c += 256) {
+    ep[0][c] = scale ? scale[c] : 1.f;
+    ep[1][c] = shift ? shift[c] : 0.f;
+    ep[2][c] = alpha ? alpha[c] : 0.f;
+    ep[3][c] = scale2 ? scale2[c] : 1.f;
+    ep[4][c] = shift2 ? shift2[c] : 0.f;
+    ep[5][c] = alpha2 ? alpha2[c] : 0.f;
+  }
+  __syncthreads();
+  const int g = tid & 3;
+  const int64_t total = (int64_t)N * H * W;
+  const float* wg = ws + g * CG;
+  const int c0 = g * CG;
+  // the block keeps its weights and walks 64-pixel groups (grid-stride): the 6.9 KB weight fetch is paid once
+  for (int64_t pix = (int64_t)blockIdx.x * 64 + (tid >> 2); pix < total; pix += (int64_t)gridDim.x * 64) {
+    // the weights are re-read from LDS for every pixel group: left alone, the compiler hoists all 27 x Cout/4 of a
+    // thread's weights out of this loop into 256 registers (one wave per SIMD: measured 9x slower)
+    asm volatile("" : : "v"(ws), "v"(ep) : "memory");   // (the arrays' addresses escape into the asm: it may have written them)
+    const int hw = (int)(pix % ((int64_t)H * W));
+    const int64_t n = pix / ((int64_t)H * W);
+    const int hq = hw / W, wq = hw - hq * W;
+    // a ROLLED loop over the nine taps (pixel load, 12 weight reads from LDS, 3 x CG fma): unrolled, the scheduler
+    // hoists the weight reads of all taps (432 registers' worth) and spills them -- measured 3x slower than the MFMA path
+    float acc[CG];
+#pragma unroll
+    for (int c = 0; c < CG; ++c) acc[c] = 0.f;
+#pragma unroll 1
+    for (int kh = 0; kh < 3; ++kh) {
+      // the three pixels of one kernel row are requested together (their latencies overlap); the tap loop stays rolled
+      const int hi = hq + kh - 1;
+      const bool hok = (unsigned)hi < (unsigned)H;
+      f32x4 vr[3];
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int wi = wq + kw - 1;
+        const bool ok = hok && (unsigned)wi < (unsigned)W;
+        const f32x4 t = *reinterpret_cast<const f32x4*>(x + ((n * H + (ok ? hi : hq)) * W + (ok ? wi : wq)) * 4);
+        vr[kw] = ok ? t : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll 1
+      for (int kw = 0; kw < 3; ++kw) {
+        const f32x4 v = kw == 0 ? vr[0] : (kw == 1 ? vr[1] : vr[2]);
+        const float* wt = wg + (kh * 3 + kw) * 3 * COUT;
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci) {
+#pragma unroll
+          for (int c4 = 0; c4 < CG; c4 += 4) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(wt + ci * COUT + c4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[c4 + j] = fmaf(v[ci], wv[j], acc[c4 + j]);
+          }
+        }
+      }
+    }
+    float* yo = y ? y + pix * COUT + c0 : nullptr;
+    float* y2o = y2 ? y2 + pix * COUT + c0 : nullptr;
+#pragma unroll
+    for (int c4 = 0; c4 < CG; c4 += 4) {
+      f32x4 o, o2;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = c0 + c4 + j;
+        float t1 = fmaf(acc[c4 + j], ep[0][c], ep[1][c]);
+        if (act == ACT_RELU) t1 = fmaxf(t1, 0.f);
+        else if (act == ACT_PRELU) t1 = t1 >= 0.f ? t1 : t1 * ep[2][c];
+        else if (act == ACT_RELU6) t1 = fminf(fmaxf(t1, 0.f), 6.f);
+        o[j] = t1;
+        float t2 = fmaf(t1, ep[3][c], ep[4][c]);
+        if (act2 == ACT_RELU) t2 = fmaxf(t2, 0.f);
+        else if (act2 == ACT_PRELU) t2 = t2 >= 0.f ? t2 : t2 * ep[5][c];
+        else if (act2 == ACT_RELU6) t2 = fminf(fmaxf(t2, 0.f), 6.f);
+        o2[j] = t2;
+      }
+      if (yo) *reinterpret_cast<f32x4*>(yo + c4) = o;
+      if (y2o) *reinterpret_cast<f32x4*>(y2o + c4) = o2;
+    }
+  }
+}
+
+int stem3x3_run(const float* x, const float* w_hwio, const float* scale, const float* shift, const float* alpha,
+                const float* scale2, const float* shift2, const float* alpha2, float* y, float* y2, int N, int H, int W,
+                int Cout, int act, int act2, hipStream_t st) {
+  const int64_t total = (int64_t)N * H * W;
+  if (total == 0) return 0;
+  int64_t groups = (total + 63) / 64;
+  const unsigned blocks = (unsigned)(groups < 4096 ? groups : 4096);     // 16 resident blocks per CU, grid-stride beyond
+  if (Cout == 32)
+    hipLaunchKernelGGL(stem3x3_kernel<32>, dim3(blocks), dim3(256), 0, st, x, w_hwio, scale, shift, alpha, scale2, shift2,
+                       alpha2, y, y2, N, H, W, act, act2);
+  else
+    return set_error("stem3x3: Cout must be 32 (got %d)", Cout);
+  DIF_HIP(hipGetLastError());
+  return 0;
+}
+
 // ---------------------------------------------------------------- GDC tail, fused
 // networks/triplet.py:129-138 after the head's first convolution: DepthwiseConv2D(kernel = whole map) -> BN ->
 // Conv2D(emd, 1) -> Dropout (identity) -> Flatten -> Dense(emd) -> l2_normalize, two images per block.  About

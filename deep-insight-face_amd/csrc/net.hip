@@ -899,6 +899,15 @@ int Net::finalize(int mb) {
           for (int co = 0; co < op.Cout; ++co) packed[(size_t)co * op.Kpad + kk] = src[co];
         }
       if (upload(this, packed, &op.d_w)) return -1;
+      // YOLOv3-face's 3-channel 3x3 first layer (32 filters) runs as a direct convolution (elementwise.hip): 0.68 ms vs
+      // 1.50 ms per 64 frames as an implicit GEMM.  IResNet's conv1 (64 filters, two outputs) measured 0.63 vs 0.57 ms:
+      // both forms are bound by its 1.6 GB of output, so it stays on the MFMA path.
+      static const bool use_stem = !(getenv("DIF_NO_STEM") && atoi(getenv("DIF_NO_STEM")));
+      op.d_w_raw = nullptr;
+      if (use_stem && op.KH == 3 && op.KW == 3 && op.stride == 1 && op.pad_t == 1 && op.pad_l == 1 && op.Cin_true == 3 &&
+          op.Cin == 4 && op.Cout == 32 && op.res < 0 && !op.pre_bn.valid() && !op.chw_flatten &&
+          tensors[op.y >= 0 ? op.y : op.y2].parent < 0 && upload(this, params[op.w].data, &op.d_w_raw))
+        return -1;
       op.d_w3 = nullptr;
       if (compute_bf16x3 && op.Cin % BK == 0 && op.Cout >= 32 && op.Cout % 4 == 0) {
         // split-bf16 mode: hi / mid / lo planes by repeated round-to-nearest-even, [Cout][Kpad/32][3][32]
@@ -1053,7 +1062,7 @@ const char* Net::kernel_name(const Op& op, int n) const {
     case OP_ZERO: return "memset";
     case OP_UPSAMPLE: return "upsample2_kernel";
     case OP_COPY: return "copy_to_view_kernel";
-    case OP_CONV: return "conv_igemm_kernel<64x64>";   // or its software-pipelined sibling conv_pipe_kernel (conv.hip)
+    case OP_CONV: return op.d_w_raw ? "stem3x3_kernel" : "conv_igemm_kernel<64x64>";   // or its software-pipelined sibling conv_pipe_kernel (conv.hip)
   }
   return "?";
 }
@@ -1153,6 +1162,12 @@ int Net::run_op(const Op& op, Lane& L, const void* xin, int n, int layout, int d
       a.sk_epoch = ++L.sk_epoch;
       a.sk_spin_limit = sk_spin_limit;
       a.use_pipe = use_pipe;
+      if (op.d_w_raw) {
+        if (stem3x3_run(a.x, op.d_w_raw, a.scale, a.shift, a.alpha, a.scale2, a.shift2, a.alpha2, a.y, a.y2, n, a.H, a.W, a.Cout,
+                        a.act, a.act2, st))
+          return -1;
+        break;
+      }
       if (conv_run(a, st)) return -1;
       break;
     }

@@ -62,6 +62,7 @@ struct Op {
   int act = ACT_NONE, act2 = ACT_NONE;
   // device side (filled by finalize)
   float* d_w = nullptr;
+  float* d_w_raw = nullptr;   // 3-channel 3x3 stem: the Keras HWIO kernel as it is, for the direct kernel
   float* d_w_pw = nullptr;
   float* d_w_dense = nullptr;
   void* d_w3 = nullptr;       // split-bf16 planes of the same matrix (compute mode bf16x3)

@@ -133,6 +133,11 @@ int dwconv_run(const float* x, const float* w, const float* scale, const float* 
 // depthwise conv whose kernel covers the whole map, + BN: y[n,c] = (sum_hw x*w) * scale + shift
 int dwfull_run(const float* x, const float* w, const float* scale, const float* shift, float* y, int N, int HW,
                int C, hipStream_t st);
+// direct 3x3 / stride 1 / pad 1 convolution of a 3-channel input held as NHWC4, Cout 32; w = Keras HWIO
+// [3][3][3][Cout]; epilogue as conv_run's
+int stem3x3_run(const float* x, const float* w_hwio, const float* scale, const float* shift, const float* alpha,
+                const float* scale2, const float* shift2, const float* alpha2, float* y, float* y2, int N, int H, int W,
+                int Cout, int act, int act2, hipStream_t st);
 // GDC head tail in one launch (networks/triplet.py:129-138): depthwise over the whole map + BN -> 1x1 conv (512 -> E) ->
 // dense (E -> E) -> l2_normalize; x [N][HW][512], w_dw [HW][512], w_pw [512][E], w_dense [E][E], y [N][E]; E <= 1024
 int gdc_tail_run(const float* x, const float* w_dw, const float* scale, const float* shift, const float* w_pw,
