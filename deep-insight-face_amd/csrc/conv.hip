@@ -1216,18 +1216,9 @@ static bool bf3_pays(const ConvArgs& a) {
   return KS >= min_ks && tiles * KS >= (int64_t)min_run * 2 * num_cus();
 }
 
-static bool conv_big_tile(const ConvArgs& a) {
-  static const int mode = getenv("DIF_CONV_TILE") ? atoi(getenv("DIF_CONV_TILE")) : 0;   // 0 never, 1 by rule, 2 wherever legal
-  if (mode == 0 || a.Cin % 4 != 0 || a.Cout % 4 != 0) return false;
-  if (mode == 2) return a.Cout >= 64;
-  static const int min_ks = getenv("DIF_BIG_MIN_KS") ? atoi(getenv("DIF_BIG_MIN_KS")) : 18;
-  return a.Cout % 128 == 0 && a.Kpad / BK >= min_ks;
-}
-
-// One tile shape ships: 64x64 (four blocks per CU).  Measured per layer over both networks in round 1
-// against 128x128 / 128x64 / 64x128: it wins or ties everywhere (four co-resident blocks keep the MFMA pipe
-// fed across each block's barriers, prologue and epilogue; the larger tiles spilled at the register budget
-// of two blocks per CU), so the other instantiations were dropped from the library.
+// The f32 path ships ONE tile shape: 64x64 (four blocks per CU).  Measured per layer over both networks against
+// 128x128 / 128x64 / 64x128 at four waves (round 1: it wins or ties everywhere) and against 128x128 at eight waves
+// (round 2: within 1 % either way, profiles/r02_ablation.txt), so the other f32 instantiations were dropped.
 int conv_run(const ConvArgs& a, hipStream_t st) {
   if (a.M <= 0) return 0;
   if (a.Cin % 4 != 0) return set_error("conv: Cin must be a multiple of 4 (got %d)", a.Cin);
@@ -1248,9 +1239,6 @@ int conv_run(const ConvArgs& a, hipStream_t st) {
     if (span * a.H * a.W * a.Cin * 4 >= 0x7fffffffLL)
       return set_error("conv: a 256-pixel tile spans more than 2 GiB of input (%dx%dx%d)", a.H, a.W, a.Cin);
   }
-  // Two tile shapes ship (see the comment above): 64x64 / 4 waves, and 128x128 / 8 waves (each wave 64x32) for
-  // layers with a long K loop and at least 128 output channels: half the operand staging, barriers and
-  // address arithmetic per MFMA at the same four waves per SIMD.
   if (a.w3 && bf3_pays(a)) {
     // split-bf16 mode (8 waves, 128x128; 256x64 for narrow layers): stream-K / one tile per block as for f32
     const bool pw = a.KH == 1 && a.KW == 1 && a.pad_t == 0 && a.pad_l == 0 && a.Cin % BK == 0;
@@ -1263,7 +1251,6 @@ int conv_run(const ConvArgs& a, hipStream_t st) {
     if (pw) return a.pre_scale ? launch_conv_pre<T, true, false, 1, true>(a, st) : launch_conv_pre<T, false, false, 1, true>(a, st);
     return a.pre_scale ? launch_conv_pre<T, true, false, 0, true>(a, st) : launch_conv_pre<T, false, false, 0, true>(a, st);
   }
-  if (conv_big_tile(a)) return launch_conv<Tile<2, 1, 2, 4>>(a, st);
   return launch_conv<Tile<1, 1>>(a, st);
 }
 

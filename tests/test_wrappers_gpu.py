@@ -178,3 +178,48 @@ def test_prediction_wrappers_keep_the_callers_transform(cuda):
     assert model._transform == (pytest.approx(1 / 255.), (0.0, 0.0, 0.0), False, False)
     assert np.array_equal(model.predict_on_batch(u8), before)
     model.close()
+
+
+def test_triplet_evaluate_object(cuda, tmp_path, capsys):
+    """evaluation/evals.py:19-78 mirror: TripletEvaluate(emd_model, image_paths, pairs)(batch_size, nrof_folds,
+    distance_metric, subtract_mean) runs the batched embedding loop and the LFW-protocol statistics; checked
+    against the oracle's calculate_roc on the same embeddings, with files on disk and with injected batches."""
+    from PIL import Image
+    from deep_insight_face.evaluation.evals import TripletEvaluate
+    from deep_insight_face.networks.triplet import DifEmbedder
+    from oracle import evalproto as oe
+    model = DifEmbedder('resnet', 'v1', 128, (112, 112, 3), max_batch=16).init_synthetic(5)
+    rng = np.random.default_rng(12)
+    npairs = 30
+    base = rng.integers(0, 256, (npairs, 112, 112, 3), dtype=np.uint8)
+    issame = rng.random(npairs) < 0.5
+    imgs = []
+    for i in range(npairs):
+        other = np.clip(base[i].astype(np.int64) + rng.integers(-20, 21, base[i].shape), 0, 255).astype(np.uint8) \
+            if issame[i] else rng.integers(0, 256, base[i].shape, dtype=np.uint8)
+        imgs += [base[i], other]
+    paths = []
+    for k, im in enumerate(imgs):
+        p = str(tmp_path / ('img%03d.png' % k))
+        Image.fromarray(im).save(p)
+        paths.append(p)
+    ev = TripletEvaluate(model, paths, issame)
+    res = ev(batch_size=16, nrof_folds=5, distance_metric=1, subtract_mean=False)
+    out = capsys.readouterr().out
+    assert 'Accuracy:' in out and 'Validation rate:' in out and 'Area Under Curve (AUC):' in out
+    x = np.stack(imgs).astype(np.float32) / np.float32(255)
+    emb = np.concatenate([model.predict_on_batch(x[s:s + 16]) for s in range(0, 2 * npairs, 16)])
+    assert cosine_gap(res['embeddings'], emb).max() < 1e-6
+    tpr, fpr, acc, f1 = oe.calculate_roc(np.arange(0, 4, 0.01), res['embeddings'][0::2], res['embeddings'][1::2], issame, 5, 1, False)
+    np.testing.assert_allclose(res['tpr'], tpr, atol=1e-12)
+    np.testing.assert_allclose(res['fpr'], fpr, atol=1e-12)
+    np.testing.assert_allclose(res['accuracy'], acc, atol=1e-12)
+    # injected batches (the reference's generator contract: y = running image index)
+    def batches(bs):
+        for s in range(0, 2 * npairs, bs):
+            yield x[s:s + bs], np.arange(s, min(s + bs, 2 * npairs))
+    res2 = TripletEvaluate(model, paths, issame, batches=batches)(16, 5, 1)
+    np.testing.assert_allclose(res2['accuracy'], res['accuracy'])
+    with pytest.raises(AssertionError, match='Wrong labels'):
+        TripletEvaluate(model, paths, issame, batches=lambda bs: [(x[:16], np.arange(1, 17))])(16, 5, 1)
+    model.close()
