@@ -84,8 +84,6 @@ class InceptionNetwork:
 
     def save_weights(self, model_dir_path: str):
         assert model_dir_path and model_dir_path.endswith((".h5", ".npz")), "Invalid weights format"
-        if model_dir_path.endswith(".h5"):
-            raise ValueError("Keras HDF5 needs h5py, which is not available here; save as .npz")
         self.model.save_weights(model_dir_path)
 
     def predict_on_batch(self, img):

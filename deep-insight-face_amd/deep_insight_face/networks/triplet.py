@@ -87,12 +87,29 @@ class DifEmbedder:
         return self
 
     def load_weights(self, path):
+        """``model.load_weights(path)`` (api.py:87, inceptionv3.py:79-82): a Keras HDF5 weight file (read with h5py
+        where it is installed, otherwise by networks/h5lite.py) or the native ``.npz`` (one entry per weight name)."""
         if str(path).endswith(('.h5', '.hdf5')):
-            raise ValueError('Keras HDF5 weights need h5py, which is not available here; convert to .npz '
-                             '(one entry per Keras weight name) and load that')
+            from . import h5lite
+            spec = dict(self.param_spec())
+            params = {}
+            for name, a in h5lite.read_keras_weights(path).items():
+                if name in spec and a.shape != spec[name] and a.size == int(np.prod(spec[name])):
+                    a = a.reshape(spec[name])          # e.g. PReLU alpha saved as (1, 1, C) with shared spatial axes
+                params[name] = a
+            self.set_weights(params)
+            return
         self.set_weights(W.load_npz(path))
 
     def save_weights(self, path):
+        if str(path).endswith(('.h5', '.hdf5')):
+            try:
+                import h5py  # noqa: F401
+            except ImportError:
+                raise ValueError('writing Keras HDF5 needs h5py, which is not installed here; save as .npz '
+                                 '(load_weights reads both)')
+            W.save_keras_h5(path, self.get_weights())
+            return
         W.save_npz(path, self.get_weights())
 
     def set_input_transform(self, scale=1.0, bias=(0.0, 0.0, 0.0), bgr=False, hflip=False):

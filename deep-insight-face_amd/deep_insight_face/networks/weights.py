@@ -50,3 +50,20 @@ def save_npz(path, params):
 def load_npz(path):
     with np.load(path) as z:
         return {k.replace('::', '/'): np.ascontiguousarray(z[k], dtype=np.float32) for k in z.files}
+
+
+def save_keras_h5(path, params):
+    """Keras ``save_weights`` layout (needs h5py): one group per layer, ``weight_names`` / ``layer_names`` attributes."""
+    import h5py
+    by_layer = {}
+    for k, v in params.items():
+        layer, w = k.rsplit('/', 1)
+        by_layer.setdefault(layer, []).append((w, v))
+    with h5py.File(path, 'w') as f:
+        f.attrs['layer_names'] = [n.encode('utf8') for n in by_layer]
+        f.attrs['backend'] = b'tensorflow'
+        for layer, ws in by_layer.items():
+            g = f.create_group(layer)
+            g.attrs['weight_names'] = [('%s/%s:0' % (layer, w)).encode('utf8') for w, _ in ws]
+            for w, v in ws:
+                g.create_dataset('%s/%s:0' % (layer, w), data=v)
