@@ -33,11 +33,12 @@ class _StepBuffers:
         self.probes = torch.empty((B, d), dtype=torch.float32, device=dev)
         # one rank's record = { float key[B]; float dist[B]; int64 idx[B]; } (include/dif.h: dif_match_merge_packed)
         self.packed = torch.empty((world, 4 * B), dtype=torch.float32, device=dev)
+        self.local = torch.empty((4 * B,), dtype=torch.float32, device=dev)      # this rank's record (not aliasing `packed`)
         self.out_idx = torch.empty((B,), dtype=torch.int64, device=dev)
         self.out_dist = torch.empty((B,), dtype=torch.float32, device=dev)
 
-    def record(self, rank, B):
-        rec = self.packed[rank]
+    def record(self, B):
+        rec = self.local
         return rec[0:B], rec[B:2 * B], rec[2 * B:4 * B].view(torch.int64)
 
 
@@ -97,12 +98,12 @@ class ShardedGallery:
             buf = self._bufs[key] = _StepBuffers(self.world, b, d, local_embeddings.device)
         B = self.world * b
         probes = self.all_gather_embeddings(local_embeddings, buf.probes)
-        k, dd, ix = buf.record(self.rank, B)
+        k, dd, ix = buf.record(B)
         if self.world == 1:
             self.gallery.match_into(probes, distance_metric, buf.out_idx, buf.out_dist)
             return buf.out_idx, buf.out_dist
         self.gallery.match_into(probes, distance_metric, ix, dd, k)
-        dist.all_gather_into_tensor(buf.packed.view(-1), buf.packed[self.rank], group=self.group)
+        dist.all_gather_into_tensor(buf.packed.view(-1), buf.local, group=self.group)
         N.check(N.lib.dif_match_merge_packed(N.ptr(buf.packed), self.world, B, N.ptr(buf.out_idx), N.ptr(buf.out_dist),
                                              N.stream_ptr()))
         return buf.out_idx, buf.out_dist
