@@ -515,7 +515,9 @@ struct EpiRes {
 // Stages the accumulator tile in LDS, then applies the epilogue with 16-byte accesses
 // along the channel axis.  Ends on a barrier (LDS is free afterwards).  `er` already holds the
 // shortcut tile when `res_loaded`.
-template <class T>
+// PRELOAD = false (the patch path, which never prefetches the shortcut tile: its registers hold the next patch): the
+// shortcut is fetched row by row inside the loop instead of all at once -- that kernel then compiles without spills.
+template <class T, bool PRELOAD = true>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T::WM][T::WN], int m0, int n0,
                                               float* smem, EpiRes<T>& er, bool res_loaded) {
   constexpr int WM = T::WM, WN = T::WN;
@@ -543,19 +545,35 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
     const bool plain_out = (a.y_H == a.Ho && a.y_W == a.Wo && a.y_oy == 0 && a.y_ox == 0);
     const f32x4 sc = load4_or(a.scale, c, 1.f), sh = load4_or(a.shift, c, 0.f), al = load4_or(a.alpha, c, 0.f);
     const f32x4 sc2 = load4_or(a.scale2, c, 1.f), sh2 = load4_or(a.shift2, c, 0.f), al2 = load4_or(a.alpha2, c, 0.f);
-    if (a.res && !res_loaded) er.load(a, m0, n0);
+    if constexpr (PRELOAD) {
+      if (a.res && !res_loaded) er.load(a, m0, n0);
+    }
+    const bool strided_res = (a.res_stride != 1 || a.res_H != a.Ho || a.res_W != a.Wo);
 #pragma unroll
     for (int i = 0; i < ITER; ++i) {
       const int rl = r0 + i * RPP;
       const int row = m0 + rl;
       if (row < a.M) {
+        f32x4 rres = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (PRELOAD) {
+          rres = er.rv[i];
+        } else if (a.res) {
+          int64_t ri = row;
+          if (strided_res) {
+            int img, rr, ho, wo;
+            a.fd_howo.divmod(row, img, rr);
+            a.fd_wo.divmod(rr, ho, wo);
+            ri = ((int64_t)img * a.res_H + (int64_t)ho * a.res_stride) * a.res_W + (int64_t)wo * a.res_stride;
+          }
+          rres = *reinterpret_cast<const f32x4*>(a.res + ri * a.Cout + c);
+        }
         const f32x4 av = *reinterpret_cast<const f32x4*>(smem + rl * CS + c4 * 4);
         f32x4 v, v2;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float t = fmaf(av[j], sc[j], sh[j]);
           t = apply_act(t, a.act, al[j]);
-          if (a.res) t += er.rv[i][j];
+          if (a.res) t += rres[j];
           v[j] = t;
           v2[j] = apply_act(fmaf(t, sc2[j], sh2[j]), a.act2, al2[j]);
         }
@@ -780,7 +798,7 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const 
         kdone = q_ke;
       }
       if (a.trace) tC = __builtin_amdgcn_s_memrealtime();
-      conv_epilogue<T>(a, acc, m0, n0, smem, er, whole);
+      conv_epilogue<T, AM != 3>(a, acc, m0, n0, smem, er, whole);
     }
     if (a.trace) {
       const unsigned long long tD = __builtin_amdgcn_s_memrealtime();
