@@ -324,15 +324,18 @@ struct ConvADmaLoader {
 // PATCH_EMAX * 128 + 2 * 64 * 128 = 37.9 KB of LDS: four blocks per CU, as before.
 // The next slice's patch is fetched into registers while taps 4..8 of the current one run, and written after a
 // barrier at the slice boundary (one extra barrier per nine K-steps).
-constexpr int PATCH_EMAX = 128;                       // entries a 64-pixel tile may need (host-checked bound): maps up to 14 wide
-constexpr int PATCH_LDS_BYTES = PATCH_EMAX * 128 + 2 * 64 * 128;
+// entries a 64-pixel tile may need (host-checked bound): two instantiations -- 128 entries cover maps up to 14 wide
+// (16 prefetch registers, no spills), 168 entries 28-wide maps (24 registers, 7 spilled: still +3.7 % on those layers)
+constexpr int PATCH_EMAX_S = 128, PATCH_EMAX_L = 168;
+constexpr int patch_lds_bytes(int emax) { return emax * 128 + 2 * 64 * 128; }
 constexpr int PATCH_PF_TAP = 4;                       // tap of the current slice at which the next patch is requested
 
 __device__ __forceinline__ int patch_swz(int entry) { return (entry >> 1) & 7; }
 
 // T: the tile (BM output pixels, NT threads); EMAX: entries of the LDS patch
-template <class T, int EMAX>
+template <class T, int EMAX_>
 struct PatchA {
+  static constexpr int EMAX = EMAX_;
   static constexpr int NPC = (EMAX * 8 + T::NT - 1) / T::NT;   // 16-byte chunks per thread per patch
   __amdgpu_buffer_rsrc_t rsrc;
   uint32_t goff[NPC];   // byte offset of this thread's chunk j inside channel slice 0, or OOB
@@ -398,7 +401,7 @@ __device__ __forceinline__ void gemm_mainloop_patch(const PA& pa, BLoader& bl, i
   static_assert(T::BM == 64 && T::BN == 64 && T::NT == 256, "patch path: 64x64 tile");
   constexpr int NB = T::NB, RP = T::RP;
   float* patch = lds;
-  float* bimg = lds + PATCH_EMAX * 32;                   // two B images of 64 rows x 32 floats
+  float* bimg = lds + PA::EMAX * 32;                     // two B images of 64 rows x 32 floats
   const int tid = threadIdx.x, lane = tid & 63;
   const int wc = T::wave_col();
   const int h = lane >> 5;
@@ -619,7 +622,7 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const 
   static_assert(!(PRE && DMA), "pre-activation needs register staging");
   static_assert(!(AM != 0 && DMA), "the specialised loaders are register-staged");
   static_assert(!(BF3 && DMA), "the split-bf16 mainloop stages through registers");
-  static_assert(AM != 3 || (!PRE && !DMA && !BF3 && T::BM == 64 && T::BN == 64), "patch path: plain f32, 64x64 tile");
+  static_assert((AM != 3 && AM != 5) || (!PRE && !DMA && !BF3 && T::BM == 64 && T::BN == 64), "patch path: plain f32, 64x64 tile");
   constexpr int WM = T::WM, WN = T::WN;
   constexpr int SLAB = T::BM * T::BN;    // floats per partial-accumulator slab
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -670,7 +673,8 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const 
     using ALoadReg = typename std::conditional<AM == 1, ConvPwLoader<T::NA, T::RP, PRE>,
                                                ConvALoader<T::NA, T::RP, PRE, AM == 2 ? 2 : 0>>::type;
     using ALoadGather = typename std::conditional<DMA, ConvADmaLoader<T::NA, T::RP>, ALoadReg>::type;
-    using ALoad = typename std::conditional<AM == 3, PatchA<T, PATCH_EMAX>, ALoadGather>::type;   // AM 3: halo-resident patch
+    using ALoad = typename std::conditional<AM == 3, PatchA<T, PATCH_EMAX_S>,                     // AM 3 / 5: halo-resident patch
+                                            typename std::conditional<AM == 5, PatchA<T, PATCH_EMAX_L>, ALoadGather>::type>::type;
     using BLoadF32 = typename std::conditional<DMA, DmaRowLoader<T::NB, T::RP>, RowLoader<T::NB, T::RP>>::type;
     using BLoad = typename std::conditional<BF3, Bf3WeightLoader<T>, BLoadF32>::type;
     ALoad al(a, m0);
@@ -682,14 +686,14 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const 
     }();
     // this block computes the whole tile: fetch the shortcut tile behind the last K-step
     // (not on the patch path: its prefetch registers leave no room, the shortcut tile would only be spilled)
-    const bool whole = !DMA && AM != 3 && kb == 0 && ke == KS;
+    const bool whole = !DMA && AM != 3 && AM != 5 && kb == 0 && ke == KS;
     EpiRes<T> er;
     auto run = [&](int k0, int k1, bool prefetch_res) {
       if constexpr (BF3)
         gemm_mainloop_bf3<T>(al, bl, k0, k1, reinterpret_cast<char*>(smem), acc, [&] {
           if (prefetch_res && a.res) er.load(a, m0, n0);
         });
-      else if constexpr (AM == 3)
+      else if constexpr (AM == 3 || AM == 5)
         gemm_mainloop_patch<T>(al, bl, k0, k1, smem, acc, [&] {
           if (prefetch_res && a.res) er.load(a, m0, n0);
         });
@@ -798,7 +802,7 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const 
         kdone = q_ke;
       }
       if (a.trace) tC = __builtin_amdgcn_s_memrealtime();
-      conv_epilogue<T, AM != 3>(a, acc, m0, n0, smem, er, whole);
+      conv_epilogue<T, (AM != 3 && AM != 5)>(a, acc, m0, n0, smem, er, whole);
     }
     if (a.trace) {
       const unsigned long long tD = __builtin_amdgcn_s_memrealtime();
@@ -1114,15 +1118,16 @@ static int launch_conv_pipe(const ConvArgs& a, hipStream_t st) {
 // 3x3 / stride 1 / pad 1, whole 32-channel slices in channel-block-major K order, plain output geometry, and a
 // 64-pixel tile's halo patch bounded by PATCH_EMAX entries (row wraps add 2 entries each, an image boundary adds
 // one padded row).  IResNet's 28x28, 14x14 and 7x7 stages qualify; 56x56 and up keep the per-K-step gather.
-static bool patch_applies(const ConvArgs& a) {
-  constexpr int BM = 64, emax = PATCH_EMAX;
+// returns 0 (no), PATCH_EMAX_S or PATCH_EMAX_L: the smallest patch size that covers every tile of the layer
+static int patch_applies(const ConvArgs& a) {
+  constexpr int BM = 64;
   static const bool on = !(getenv("DIF_NO_PATCH") && atoi(getenv("DIF_NO_PATCH")));
-  if (!on || a.pre_scale || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad_t != 1 || a.pad_l != 1) return false;
-  if (a.Cin % BK != 0 || a.k_order != 1 || a.Ho != a.H || a.Wo != a.W) return false;
+  if (!on || a.pre_scale || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad_t != 1 || a.pad_l != 1) return 0;
+  if (a.Cin % BK != 0 || a.k_order != 1 || a.Ho != a.H || a.Wo != a.W) return 0;
   const int HW = a.H * a.W, WP = a.W + 2;
   const int row_wraps = (BM - 2) / a.W + 1, img_wraps = a.N > 1 ? (BM - 2) / HW + 1 : 0;
   const int e_bound = (BM - 1) + 2 * row_wraps + WP * img_wraps + 2 * WP + 4;
-  return e_bound <= emax;
+  return e_bound <= PATCH_EMAX_S ? PATCH_EMAX_S : (e_bound <= PATCH_EMAX_L ? PATCH_EMAX_L : 0);
 }
 
 static bool pipe_applies(const ConvArgs& a, int64_t tiles, int KS, int64_t slots) {
@@ -1168,7 +1173,11 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
   if (pw && a.pre_scale) return launch_conv_pre<T, true, false, 1>(a, st);
   if (pw) return launch_conv_pre<T, false, false, 1>(a, st);
   if constexpr (kDefaultTile) {
-    if (!use_dma && patch_applies(a)) return launch_conv_pre<T, false, false, 3>(a, st);
+    if (!use_dma) {
+      const int emax = patch_applies(a);
+      if (emax == PATCH_EMAX_S) return launch_conv_pre<T, false, false, 3>(a, st);
+      if (emax == PATCH_EMAX_L) return launch_conv_pre<T, false, false, 5>(a, st);
+    }
   }
   if (a.pre_scale) return launch_conv_pre<T, true, false, 0>(a, st);
   if (use_dma) return launch_conv_pre<T, false, true, 0>(a, st);
@@ -1178,7 +1187,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
 template <class T, bool PRE, bool DMA, int AM, bool BF3>
 static int launch_conv_pre(const ConvArgs& a, hipStream_t st) {
   auto kern = conv_igemm_kernel<T, PRE, DMA, AM, BF3>;
-  constexpr int lds_bytes = BF3 ? Bf3<T>::LDS_BYTES : (AM == 3 ? PATCH_LDS_BYTES : T::LDS_BYTES);
+  constexpr int lds_bytes = BF3 ? Bf3<T>::LDS_BYTES : (AM == 3 ? patch_lds_bytes(PATCH_EMAX_S) : (AM == 5 ? patch_lds_bytes(PATCH_EMAX_L) : T::LDS_BYTES));
   if (allow_dynamic_lds(kern, lds_bytes)) return -1;
   const int64_t tiles = ((a.M + T::BM - 1) / T::BM) * (int64_t)((a.Cout + T::BN - 1) / T::BN);
   const int KS = a.Kpad / BK;
