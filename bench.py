@@ -417,8 +417,8 @@ def main():
         achieved = flops_embed / (embed_ms * 1e-3) / 1e12
         prof = model.profile(crops)
         det_ops = det.op_table() if pipe is not None else []
-        conv_ms = sum(ms for _, k, _, ms in prof if k.startswith(('conv_igemm', 'stem3x3')))
-        conv_flops = sum(2 * macs * batch for _, k, macs, _ in prof if k.startswith(('conv_igemm', 'stem3x3')))
+        conv_ms = sum(ms for _, k, _, ms in prof if k.startswith(('conv_igemm', 'stem')))
+        conv_flops = sum(2 * macs * batch for _, k, macs, _ in prof if k.startswith(('conv_igemm', 'stem')))
         out = {
             'metric': 'faces/sec embedding+match (112x112, 512-d)' if pipe is None else
                       'frames/sec detect+crop+embed+match (640x480 frames, one face per frame)',
@@ -443,9 +443,9 @@ def main():
             'roofline': {
                 'bound': 'mfma', 'kernel': 'conv_igemm_kernel + conv_pipe_kernel (f32 MFMA implicit-GEMM conv; one launch group = the '
                                            '%d conv launches of one %s forward at batch %d%s)'
-                                           % (sum(1 for _, k, _, _ in prof if k.startswith(('conv_igemm', 'stem3x3'))), arch, batch,
+                                           % (sum(1 for _, k, _, _ in prof if k.startswith(('conv_igemm', 'stem'))), arch, batch,
                                               '' if pipe is None else ' + the %d conv launches of the YOLOv3-face detector per chunk of 64 frames'
-                                              % sum(1 for _, k, _ in det_ops if k.startswith(('conv_igemm', 'stem3x3')))),
+                                              % sum(1 for _, k, _ in det_ops if k.startswith(('conv_igemm', 'stem')))),
                 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': measured_traffic(args.workload, batch),
                 'traffic_unit': 'HBM bytes per forward (rocprofv3 PMC, profiles/)',

@@ -393,6 +393,61 @@ struct PatchA {
   }
 };
 
+// The same operand for maps whose height and width are multiples of 8 (the 56x56 and 112x112 stages): the 64 output
+// pixels of a tile are an 8x8 SQUARE of one image (AM = 6), so the patch is 10x10 = 100 entries whatever the map's
+// width -- a linear 64-pixel run on a 56-wide map would need 245.  Entry (py, px) = input pixel (h0 - 1 + py,
+// w0 - 1 + px); tile row r = output pixel (h0 + r / 8, w0 + r % 8); tap (kh, kw) = entry offset kh * 10 + kw.
+template <class T>
+struct PatchA2D {
+  static constexpr int EMAX = 100, SIDE = 10;
+  static constexpr int NPC = (EMAX * 8 + T::NT - 1) / T::NT;
+  __amdgpu_buffer_rsrc_t rsrc;
+  uint32_t goff[NPC];
+  int base[T::WM];
+  int WP;
+  // first output pixel (linear index) of tile m0 / 64
+  static __device__ __forceinline__ int pix0(const ConvArgs& a, int m0, int& n, int& h0, int& w0) {
+    int r, hb, wb;
+    a.fd_t2_img.divmod(m0 >> 6, n, r);
+    a.fd_t2_w.divmod(r, hb, wb);
+    h0 = hb * 8;
+    w0 = wb * 8;
+    return (n * a.H + h0) * a.W + w0;
+  }
+  __device__ __forceinline__ PatchA2D(const ConvArgs& a, int m0) {
+    static_assert(T::WM == 1 && T::BM == 64, "2-D patch: 64-pixel tile, one 32-row fragment per wave");
+    const int tid = threadIdx.x, lane = tid & 63;
+    WP = SIDE;
+    int n, h0, w0;
+    pix0(a, m0, n, h0, w0);
+    const int64_t img_elems = (int64_t)a.H * a.W * a.Cin;
+    rsrc = make_rsrc(a.x + n * img_elems, (uint32_t)(img_elems * 4));
+    const int r = T::wave_row() * 32 + (lane & 31);
+    base[0] = (r >> 3) * SIDE + (r & 7);
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      const int slot = tid + T::NT * j;
+      const int e = slot >> 3, q = slot & 7;
+      const int py = (e * 205) >> 11, px = e - py * SIDE;      // e / 10 for e < 1024
+      const int hi = h0 - 1 + py, wi = w0 - 1 + px;
+      const bool ok = e < EMAX && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+      const int chunk = q ^ patch_swz(e);
+      goff[j] = ok ? (uint32_t)((hi * a.W + wi) * a.Cin * 4 + chunk * 16) : OOB;
+    }
+  }
+  __device__ __forceinline__ void load(int cblk, f32x4 (&r)[NPC]) const {
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) r[j] = buf_load4(rsrc, goff[j] == OOB ? OOB : goff[j] + (uint32_t)cblk * 128u);
+  }
+  __device__ __forceinline__ void store(float* patch, const f32x4 (&r)[NPC]) const {
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      const int slot = threadIdx.x + T::NT * j;
+      if (slot < EMAX * 8) *reinterpret_cast<f32x4*>(patch + slot * 4) = r[j];
+    }
+  }
+};
+
 // Mainloop of the patch path: K-step ks = (channel slice ks / 9, tap ks % 9) -- the channel-block-major K order.
 // 64x64 tile, 4 waves (Tile<1,1,2,2>).  Ends on a barrier.
 template <class T, class PA, class BLoader, class Tail>
@@ -520,7 +575,8 @@ struct EpiRes {
 // shortcut tile when `res_loaded`.
 // PRELOAD = false (the patch path, which never prefetches the shortcut tile: its registers hold the next patch): the
 // shortcut is fetched row by row inside the loop instead of all at once -- that kernel then compiles without spills.
-template <class T, bool PRELOAD = true>
+// TILE2D (AM = 6): tile row r is output pixel (h0 + r / 8, w0 + r % 8) of one image instead of pixel m0 + r.
+template <class T, bool PRELOAD = true, bool TILE2D = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T::WM][T::WN], int m0, int n0,
                                               float* smem, EpiRes<T>& er, bool res_loaded) {
   constexpr int WM = T::WM, WN = T::WN;
@@ -552,10 +608,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
       if (a.res && !res_loaded) er.load(a, m0, n0);
     }
     const bool strided_res = (a.res_stride != 1 || a.res_H != a.Ho || a.res_W != a.Wo);
+    int t2_pix0 = 0;
+    if constexpr (TILE2D) {
+      int n, h0, w0;
+      t2_pix0 = PatchA2D<T>::pix0(a, m0, n, h0, w0);
+    }
 #pragma unroll
     for (int i = 0; i < ITER; ++i) {
       const int rl = r0 + i * RPP;
-      const int row = m0 + rl;
+      const int row = TILE2D ? t2_pix0 + (rl >> 3) * a.W + (rl & 7) : m0 + rl;
       if (row < a.M) {
         f32x4 rres = {0.f, 0.f, 0.f, 0.f};
         if constexpr (PRELOAD) {
@@ -589,8 +650,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
           a.fd_wo.divmod(rr, ho, wo);
           o = (((int64_t)img * a.y_H + ho + a.y_oy) * a.y_W + wo + a.y_ox) * a.y_ld + a.y_coff + c;
         }
+        int64_t oy = o;
+        bool y_on = a.y != nullptr;
+        if (a.y_sub) {
+          int img, rr, ho, wo;
+          a.fd_howo.divmod(row, img, rr);
+          a.fd_wo.divmod(rr, ho, wo);
+          y_on = y_on && !((ho | wo) & 1);
+          oy = (((int64_t)img * ((a.Ho + 1) >> 1) + (ho >> 1)) * ((a.Wo + 1) >> 1) + (wo >> 1)) * a.Cout + c;
+        }
         if (a.Cout % 4 == 0) {
-          if (a.y) *reinterpret_cast<f32x4*>(a.y + o) = v;
+          if (y_on) *reinterpret_cast<f32x4*>(a.y + oy) = v;
           if (a.y2) *reinterpret_cast<f32x4*>(a.y2 + o) = v2;
         } else {
           // narrow heads whose channel count is not a multiple of 4 (e.g. 18 = 3*(5+1) YOLO
@@ -622,7 +692,8 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const 
   static_assert(!(PRE && DMA), "pre-activation needs register staging");
   static_assert(!(AM != 0 && DMA), "the specialised loaders are register-staged");
   static_assert(!(BF3 && DMA), "the split-bf16 mainloop stages through registers");
-  static_assert((AM != 3 && AM != 5) || (!PRE && !DMA && !BF3 && T::BM == 64 && T::BN == 64), "patch path: plain f32, 64x64 tile");
+  static_assert((AM != 3 && AM != 5 && AM != 6) || (!PRE && !DMA && !BF3 && T::BM == 64 && T::BN == 64), "patch path: plain f32, 64x64 tile");
+  constexpr bool PATCH = (AM == 3 || AM == 5 || AM == 6);
   constexpr int WM = T::WM, WN = T::WN;
   constexpr int SLAB = T::BM * T::BN;    // floats per partial-accumulator slab
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -673,8 +744,9 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const 
     using ALoadReg = typename std::conditional<AM == 1, ConvPwLoader<T::NA, T::RP, PRE>,
                                                ConvALoader<T::NA, T::RP, PRE, AM == 2 ? 2 : 0>>::type;
     using ALoadGather = typename std::conditional<DMA, ConvADmaLoader<T::NA, T::RP>, ALoadReg>::type;
-    using ALoad = typename std::conditional<AM == 3, PatchA<T, PATCH_EMAX_S>,                     // AM 3 / 5: halo-resident patch
-                                            typename std::conditional<AM == 5, PatchA<T, PATCH_EMAX_L>, ALoadGather>::type>::type;
+    using ALoadLin = typename std::conditional<AM == 3, PatchA<T, PATCH_EMAX_S>,                  // AM 3 / 5 / 6: halo-resident patch
+                                               typename std::conditional<AM == 5, PatchA<T, PATCH_EMAX_L>, ALoadGather>::type>::type;
+    using ALoad = typename std::conditional<AM == 6, PatchA2D<T>, ALoadLin>::type;
     using BLoadF32 = typename std::conditional<DMA, DmaRowLoader<T::NB, T::RP>, RowLoader<T::NB, T::RP>>::type;
     using BLoad = typename std::conditional<BF3, Bf3WeightLoader<T>, BLoadF32>::type;
     ALoad al(a, m0);
@@ -686,14 +758,14 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const 
     }();
     // this block computes the whole tile: fetch the shortcut tile behind the last K-step
     // (not on the patch path: its prefetch registers leave no room, the shortcut tile would only be spilled)
-    const bool whole = !DMA && AM != 3 && AM != 5 && kb == 0 && ke == KS;
+    const bool whole = !DMA && !PATCH && kb == 0 && ke == KS;
     EpiRes<T> er;
     auto run = [&](int k0, int k1, bool prefetch_res) {
       if constexpr (BF3)
         gemm_mainloop_bf3<T>(al, bl, k0, k1, reinterpret_cast<char*>(smem), acc, [&] {
           if (prefetch_res && a.res) er.load(a, m0, n0);
         });
-      else if constexpr (AM == 3 || AM == 5)
+      else if constexpr (PATCH)
         gemm_mainloop_patch<T>(al, bl, k0, k1, smem, acc, [&] {
           if (prefetch_res && a.res) er.load(a, m0, n0);
         });
@@ -802,7 +874,7 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const 
         kdone = q_ke;
       }
       if (a.trace) tC = __builtin_amdgcn_s_memrealtime();
-      conv_epilogue<T, (AM != 3 && AM != 5)>(a, acc, m0, n0, smem, er, whole);
+      conv_epilogue<T, !PATCH, AM == 6>(a, acc, m0, n0, smem, er, whole);
     }
     if (a.trace) {
       const unsigned long long tD = __builtin_amdgcn_s_memrealtime();
@@ -1130,9 +1202,20 @@ static int patch_applies(const ConvArgs& a) {
   return e_bound <= PATCH_EMAX_S ? PATCH_EMAX_S : (e_bound <= PATCH_EMAX_L ? PATCH_EMAX_L : 0);
 }
 
+// the 8x8-tile form of the patch path (AM = 6): the same layers on maps whose sides are multiples of 8, where the
+// linear patch would not fit (IResNet's 112x112 and 56x56 layers, VGG16's, the detector's 208 / 104 stages)
+static bool patch2d_applies(const ConvArgs& a) {
+  static const bool on = !(getenv("DIF_NO_PATCH2D") && atoi(getenv("DIF_NO_PATCH2D")));
+  if (!on || a.pre_scale || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad_t != 1 || a.pad_l != 1) return false;
+  if (a.Cin % BK != 0 || a.k_order != 1 || a.Ho != a.H || a.Wo != a.W) return false;
+  if ((int64_t)a.H * a.W * a.Cin * 4 >= 0x7fffffffLL) return false;      // one image per buffer descriptor
+  return a.H % 8 == 0 && a.W % 8 == 0 && patch_applies(a) == 0;
+}
+
 static bool pipe_applies(const ConvArgs& a, int64_t tiles, int KS, int64_t slots) {
   static const int sk_min_ks = getenv("DIF_SK_MIN_KS") ? atoi(getenv("DIF_SK_MIN_KS")) : 32;
   if (!a.use_pipe) return false;                                      // dif_net_set_option("pipe", 0)
+  if (a.y_sub) return false;                                          // its stores know one output geometry
   if (slots < 8) return false;                                        // the kernel deals tiles out per XCD (8 of them)
   if (KS >= sk_min_ks && tiles < 8 * slots) return false;           // long K, few tiles: stream-K's case
   if (tiles < slots + slots / 2) return false;                        // fewer than ~1.5 tiles per block: nothing to overlap
@@ -1161,6 +1244,9 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
     const int64_t tiles = ((a.M + T::BM - 1) / T::BM) * (int64_t)((a.Cout + T::BN - 1) / T::BN);
     int64_t slots = 4 * (int64_t)num_cus();
     if (slots > a.sk_max_blocks) slots = a.sk_max_blocks;
+    // DIF_PATCH2D_FIRST=0: the pipelined kernel keeps the short-K 3x3 layers (64 input channels) it took before
+    static const bool p2d_first = !(getenv("DIF_PATCH2D_FIRST") && !atoi(getenv("DIF_PATCH2D_FIRST")));
+    if (!use_dma && p2d_first && patch2d_applies(a)) return launch_conv_pre<T, false, false, 6>(a, st);
     if (!use_dma && a.Cin % 4 == 0 && pipe_applies(a, tiles, a.Kpad / BK, slots)) {
       // pointwise layers retire the previous tile four chunks per K-step, i.e. within the first two
       // steps (measured best for every K: 2 steps +16 %, 8 steps +5 % over one chunk per step); the
@@ -1177,6 +1263,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
       const int emax = patch_applies(a);
       if (emax == PATCH_EMAX_S) return launch_conv_pre<T, false, false, 3>(a, st);
       if (emax == PATCH_EMAX_L) return launch_conv_pre<T, false, false, 5>(a, st);
+      if (patch2d_applies(a)) return launch_conv_pre<T, false, false, 6>(a, st);
     }
   }
   if (a.pre_scale) return launch_conv_pre<T, true, false, 0>(a, st);
@@ -1187,7 +1274,9 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
 template <class T, bool PRE, bool DMA, int AM, bool BF3>
 static int launch_conv_pre(const ConvArgs& a, hipStream_t st) {
   auto kern = conv_igemm_kernel<T, PRE, DMA, AM, BF3>;
-  constexpr int lds_bytes = BF3 ? Bf3<T>::LDS_BYTES : (AM == 3 ? patch_lds_bytes(PATCH_EMAX_S) : (AM == 5 ? patch_lds_bytes(PATCH_EMAX_L) : T::LDS_BYTES));
+  constexpr int lds_bytes = BF3 ? Bf3<T>::LDS_BYTES
+                                : (AM == 3 ? patch_lds_bytes(PATCH_EMAX_S)
+                                           : (AM == 5 ? patch_lds_bytes(PATCH_EMAX_L) : (AM == 6 ? patch_lds_bytes(100) : T::LDS_BYTES)));
   if (allow_dynamic_lds(kern, lds_bytes)) return -1;
   const int64_t tiles = ((a.M + T::BM - 1) / T::BM) * (int64_t)((a.Cout + T::BN - 1) / T::BN);
   const int KS = a.Kpad / BK;
@@ -1223,6 +1312,8 @@ static int launch_conv_pre(const ConvArgs& a, hipStream_t st) {
   b.fd_taps = make_fastdiv(a.KH * a.KW);
   b.fd_wp = make_fastdiv(a.W + 2);
   b.fd_rpi = make_fastdiv(a.H + 1);
+  b.fd_t2_w = make_fastdiv(a.W / 8 > 0 ? a.W / 8 : 1);
+  b.fd_t2_img = make_fastdiv((a.H / 8) * (a.W / 8) > 0 ? (a.H / 8) * (a.W / 8) : 1);
   if (a.k_order == 1 && a.Cin % BK != 0) return set_error("conv: channel-block-major K order needs Cin %% 32 == 0");
   b.fd_tiles_n = make_fastdiv((a.Cout + T::BN - 1) / T::BN);
   hipLaunchKernelGGL(kern, dim3((unsigned)P), dim3(T::NT), lds_bytes, st, b);
@@ -1256,6 +1347,8 @@ int conv_run(const ConvArgs& a, hipStream_t st) {
   }
   if (a.y_ld < a.y_coff + a.Cout || a.y_H < a.Ho + a.y_oy || a.y_W < a.Wo + a.y_ox)
     return set_error("conv: output view does not fit its parent tensor");
+  if (a.y_sub && (a.Cout % 4 != 0 || a.y_ld != a.Cout || a.y_H != a.Ho || a.y_W != a.Wo))
+    return set_error("conv: a subsampled first output needs a plain output geometry");
   if (a.Kpad % BK != 0) return set_error("conv: Kpad must be a multiple of %d", BK);
   if (a.H >= 0x3f00 || a.W >= 0x3f00) return set_error("conv: spatial size too large");
   if ((a.pre_scale == nullptr) != (a.pre_shift == nullptr)) return set_error("conv: pre_scale and pre_shift go together");

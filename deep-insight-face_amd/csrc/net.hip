@@ -899,15 +899,20 @@ int Net::finalize(int mb) {
           for (int co = 0; co < op.Cout; ++co) packed[(size_t)co * op.Kpad + kk] = src[co];
         }
       if (upload(this, packed, &op.d_w)) return -1;
-      // YOLOv3-face's 3-channel 3x3 first layer (32 filters) runs as a direct convolution (elementwise.hip): 0.68 ms vs
-      // 1.50 ms per 64 frames as an implicit GEMM.  IResNet's conv1 (64 filters, two outputs) measured 0.63 vs 0.57 ms:
-      // both forms are bound by its 1.6 GB of output, so it stays on the MFMA path.
+      // 3-channel first layers leave the general kernel.  YOLOv3-face's 3x3 (32 filters) runs as a direct convolution
+      // (elementwise.hip): 0.68 ms vs 1.50 ms per 64 frames as an implicit GEMM.  The 64-filter ones (IResNet conv1 3x3,
+      // ResNet50V2 conv1_conv 7x7 / 2) run on the MFMA with the true K and the input patch in LDS (stem.hip).
       static const bool use_stem = !(getenv("DIF_NO_STEM") && atoi(getenv("DIF_NO_STEM")));
       op.d_w_raw = nullptr;
-      if (use_stem && op.KH == 3 && op.KW == 3 && op.stride == 1 && op.pad_t == 1 && op.pad_l == 1 && op.Cin_true == 3 &&
-          op.Cin == 4 && op.Cout == 32 && op.res < 0 && !op.pre_bn.valid() && !op.chw_flatten &&
-          tensors[op.y >= 0 ? op.y : op.y2].parent < 0 && upload(this, params[op.w].data, &op.d_w_raw))
-        return -1;
+      op.stem_mfma = false;
+      const bool stem_shape = use_stem && op.Cin_true == 3 && op.Cin == 4 && op.res < 0 && !op.pre_bn.valid() &&
+                              !op.chw_flatten && tensors[op.y >= 0 ? op.y : op.y2].parent < 0;
+      if (stem_shape && op.KH == 3 && op.KW == 3 && op.stride == 1 && op.pad_t == 1 && op.pad_l == 1 && op.Cout == 32) {
+        if (upload(this, params[op.w].data, &op.d_w_raw)) return -1;
+      } else if (stem_shape && stem_mfma_applies(op.KH, op.KW, op.stride, op.pad_t, op.pad_l, op.Cout)) {
+        if (upload(this, params[op.w].data, &op.d_w_raw)) return -1;
+        op.stem_mfma = true;
+      }
       op.d_w3 = nullptr;
       if (compute_bf16x3 && op.Cin % BK == 0 && op.Cout >= 32 && op.Cout % 4 == 0) {
         // split-bf16 mode: hi / mid / lo planes by repeated round-to-nearest-even, [Cout][Kpad/32][3][32]
@@ -960,6 +965,36 @@ int Net::finalize(int mb) {
       if (!shift.empty() && upload(this, shift, &op.d_shift2)) return -1;
       if (op.alpha2 >= 0 && upload(this, params[op.alpha2].data, &op.d_alpha2)) return -1;
     }
+  }
+
+  // ---- outputs read only at stride 2.  A two-output convolution whose FIRST output feeds nothing but a 1x1 / stride 2
+  // convolution (IResNet: conv1's activation and the last block of a stage feed the next stage's downsample shortcut,
+  // while the batch-normalised second output feeds its 3x3) writes that output subsampled -- a quarter of the bytes;
+  // the stem's 822 MB output at batch 256 was the layer's bound -- and the reader runs at stride 1 on the dense quarter.
+  static const bool sub_on = !(getenv("DIF_NO_YSUB") && atoi(getenv("DIF_NO_YSUB")));
+  for (Op& P : ops) {
+    if (!sub_on || P.kind != OP_CONV || P.y < 0 || P.y2 < 0 || P.y_sub || is_output(P.y) || tensors[P.y].parent >= 0 ||
+        tensors[P.y2].parent >= 0 || P.Cout % 4 != 0)
+      continue;
+    bool viewed = false;
+    for (const TensorDesc& t : tensors) viewed |= t.parent == P.y;
+    Op* reader = nullptr;
+    int readers = 0;
+    for (Op& D : ops) {
+      if (&D == &P) continue;
+      const int uses = (D.x == P.y) + (D.res == P.y) + (D.y == P.y) + (D.y2 == P.y);
+      if (uses) {
+        readers += uses;
+        reader = &D;
+      }
+    }
+    if (viewed || readers != 1 || reader->kind != OP_CONV || reader->x != P.y) continue;
+    if (reader->KH != 1 || reader->KW != 1 || reader->stride != 2 || reader->pad_t != 0 || reader->pad_l != 0) continue;
+    TensorDesc& t = tensors[P.y];
+    P.y_sub = true;
+    t.H = (t.H + 1) / 2;
+    t.W = (t.W + 1) / 2;
+    reader->stride = 1;
   }
 
   // ---- activation buffers: liveness over the op list, first-fit reuse
@@ -1062,7 +1097,7 @@ const char* Net::kernel_name(const Op& op, int n) const {
     case OP_ZERO: return "memset";
     case OP_UPSAMPLE: return "upsample2_kernel";
     case OP_COPY: return "copy_to_view_kernel";
-    case OP_CONV: return op.d_w_raw ? "stem3x3_kernel" : "conv_igemm_kernel<64x64>";   // or its software-pipelined sibling conv_pipe_kernel (conv.hip)
+    case OP_CONV: return op.d_w_raw && use_stem ? (op.stem_mfma ? "stem_mfma_kernel" : "stem3x3_kernel") : "conv_igemm_kernel<64x64>";   // or its software-pipelined sibling conv_pipe_kernel (conv.hip)
   }
   return "?";
 }
@@ -1094,7 +1129,7 @@ int Net::run_op(const Op& op, Lane& L, const void* xin, int n, int layout, int d
     }
     case OP_CONV: {
       const TensorDesc& xd = tensors[op.x];
-      const TensorDesc& yd = tensors[op.y >= 0 ? op.y : op.y2];
+      const TensorDesc& yd = tensors[op.y >= 0 && !op.y_sub ? op.y : op.y2];
       ConvArgs a;
       memset(&a, 0, sizeof(a));
       a.x = ptr(op.x);
@@ -1129,6 +1164,7 @@ int Net::run_op(const Op& op, Lane& L, const void* xin, int n, int layout, int d
       a.M = n * yd.H * yd.W;
       a.act = op.act;
       a.act2 = op.act2;
+      a.y_sub = op.y_sub;
       if (op.res >= 0) {
         a.res_H = tensors[op.res].H;
         a.res_W = tensors[op.res].W;
@@ -1162,7 +1198,13 @@ int Net::run_op(const Op& op, Lane& L, const void* xin, int n, int layout, int d
       a.sk_epoch = ++L.sk_epoch;
       a.sk_spin_limit = sk_spin_limit;
       a.use_pipe = use_pipe;
-      if (op.d_w_raw) {
+      if (op.d_w_raw && op.stem_mfma && use_stem) {
+        if (stem_mfma_run(a.x, op.d_w_raw, a.scale, a.shift, a.alpha, a.scale2, a.shift2, a.alpha2, a.y, a.y2, n, a.H, a.W,
+                          a.Ho, a.Wo, a.KH, a.stride, a.act, a.act2, a.y_sub, st))
+          return -1;
+        break;
+      }
+      if (op.d_w_raw && use_stem) {
         if (stem3x3_run(a.x, op.d_w_raw, a.scale, a.shift, a.alpha, a.scale2, a.shift2, a.alpha2, a.y, a.y2, n, a.H, a.W, a.Cout,
                         a.act, a.act2, st))
           return -1;

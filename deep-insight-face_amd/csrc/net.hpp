@@ -48,6 +48,7 @@ struct Op {
   int KH = 1, KW = 1, stride = 1, pad_t = 0, pad_l = 0;
   int Cin = 0, Cin_true = 0, Cout = 0;
   int res_stride = 1;
+  bool y_sub = false;         // output y keeps its even pixels only (finalize: its one reader is a 1x1 / stride 2 convolution)
   int zero_pad = 0;
   int pool_mode = POOL_MAX;
   float const_alpha = 0.f;    // act == ACT_PRELU with one slope for every channel (LeakyReLU)
@@ -62,7 +63,8 @@ struct Op {
   int act = ACT_NONE, act2 = ACT_NONE;
   // device side (filled by finalize)
   float* d_w = nullptr;
-  float* d_w_raw = nullptr;   // 3-channel 3x3 stem: the Keras HWIO kernel as it is, for the direct kernel
+  float* d_w_raw = nullptr;   // 3-channel first layer: the Keras HWIO kernel as it is, for the stem kernels
+  bool stem_mfma = false;     // d_w_raw feeds stem.hip's MFMA kernel (64 filters) instead of elementwise.hip's direct one (32)
   float* d_w_pw = nullptr;
   float* d_w_dense = nullptr;
   void* d_w3 = nullptr;       // split-bf16 planes of the same matrix (compute mode bf16x3)
@@ -126,6 +128,7 @@ struct Net {
   int sk_spin_limit = 1 << 18;
   int compute_bf16x3 = 0;           // option "bf16x3" (set before finalize): convolutions on the split-bf16 MFMA path
   int use_pipe = 1;                 // option "pipe": 0 keeps every convolution on conv_igemm_kernel
+  int use_stem = 1;                 // option "stem": 0 runs 3-channel first layers on conv_igemm_kernel too
 
   ~Net();
   int build();                       // dispatch on arch/head

@@ -97,6 +97,10 @@ int dif_net_set_option(dif_net* h, const char* key, int value) {
     h->net.use_pipe = value != 0;
     return 0;
   }
+  if (!strcmp(key, "stem")) {
+    h->net.use_stem = value != 0;
+    return 0;
+  }
   if (!strcmp(key, "bf16x3")) {
     if (h->net.finalized && h->net.compute_bf16x3 != (value != 0))
       return set_error("dif_net_set_option: 'bf16x3' must be chosen before dif_net_finalize");

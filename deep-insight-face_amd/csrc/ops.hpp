@@ -70,6 +70,9 @@ struct ConvArgs {
   //   y[((n*y_H + ho + y_oy)*y_W + wo + y_ox)*y_ld + y_coff + c]
   // Plain output: y_ld = Cout, y_coff = 0, y_H = Ho, y_W = Wo, y_oy = y_ox = 0.
   int y_ld, y_coff, y_H, y_W, y_oy, y_ox;
+  // y_sub = 1: y (not y2) keeps only the pixels with even ho and wo, as a dense [N, (Ho+1)/2, (Wo+1)/2, Cout] tensor --
+  // its only reader is a 1x1 / stride 2 convolution (net.hip: finalize), which then runs at stride 1
+  int y_sub;
   // stream-K workspace (owned by the caller): one partial-accumulator slab and one flag per
   // persistent block; sk_epoch is unique per launch so flags never need clearing
   float* sk_slab;
@@ -86,6 +89,7 @@ struct ConvArgs {
   // launch-invariant divisors (filled by conv_run)
   FastDiv fd_howo, fd_wo, fd_cin, fd_kw, fd_ks, fd_tiles_n, fd_taps;
   FastDiv fd_wp, fd_rpi;   // halo-patch path (conv.hip: PatchA): padded row width W + 2, padded rows per image H + 1
+  FastDiv fd_t2_w, fd_t2_img;   // its 8x8-tile form (PatchA2D): tiles per row W / 8, tiles per image (H / 8) * (W / 8)
 };
 
 int conv_max_blocks();        // persistent blocks the kernel may use on this device
@@ -138,6 +142,12 @@ int dwfull_run(const float* x, const float* w, const float* scale, const float* 
 int stem3x3_run(const float* x, const float* w_hwio, const float* scale, const float* shift, const float* alpha,
                 const float* scale2, const float* shift2, const float* alpha2, float* y, float* y2, int N, int H, int W,
                 int Cout, int act, int act2, hipStream_t st);
+// 3-channel first layers with 64 filters on the MFMA, input patch resident in LDS (stem.hip): 3x3 / stride 1 / pad 1 and
+// 7x7 / stride 2 / pad 3; x NHWC4, w = Keras HWIO [KH][KW][3][64], plain [N,Ho,Wo,64] outputs; epilogue as conv_run's
+bool stem_mfma_applies(int KH, int KW, int stride, int pad_t, int pad_l, int Cout);
+int stem_mfma_run(const float* x, const float* w_hwio, const float* scale, const float* shift, const float* alpha,
+                  const float* scale2, const float* shift2, const float* alpha2, float* y, float* y2, int N, int H, int W,
+                  int Ho, int Wo, int KH, int stride, int act, int act2, int y_sub, hipStream_t st);
 // GDC head tail in one launch (networks/triplet.py:129-138): depthwise over the whole map + BN -> 1x1 conv (512 -> E) ->
 // dense (E -> E) -> l2_normalize; x [N][HW][512], w_dw [HW][512], w_pw [512][E], w_dense [E][E], y [N][E]; E <= 1024
 int gdc_tail_run(const float* x, const float* w_dw, const float* scale, const float* shift, const float* w_pw,

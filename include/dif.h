@@ -153,6 +153,8 @@ int dif_net_finalize(dif_net* net, int max_batch);
 /* execution options (no reference counterpart: Keras picks its kernels by itself).  Keys:
  *   "pipe"  1 (default) lets short-K convolutions take the software-pipelined kernel, 0 keeps every
  *           convolution on the plain implicit-GEMM kernel (the two are compared by the parity tests)
+ *   "stem"  1 (default) runs 3-channel first layers on their own kernels (stem.hip, elementwise.hip), 0 on the general
+ *           implicit-GEMM kernel (compared by the parity tests)
  *   "bf16x3" 0 (default): float32 MFMA, a bit-exact f32 fma chain -- the reference's arithmetic;
  *           1 (before dif_net_finalize): throughput mode -- every f32 operand split into three bf16 terms, six
  *           bf16 MFMA products accumulated in f32 (f32-level accuracy, same 1e-5 cosine gate, not bit-identical) */

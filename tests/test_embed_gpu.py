@@ -266,6 +266,37 @@ def test_pipelined_kernel_equals_plain_kernel(cuda, monkeypatch):
         m.close()
 
 
+def test_stem_kernels_equal_general_kernel(cuda):
+    """3-channel first layers run on their own kernels: IResNet's 3x3 and ResNet50V2's 7x7 / stride 2 (64 filters) on
+    the MFMA with the input patch in LDS and the true K (stem.hip), YOLOv3-face's 3x3 (32 filters) as a direct
+    convolution.  Option 'stem' = 0 sends them through the general implicit-GEMM kernel instead: same products, another
+    summation order, so the outputs agree to float32 rounding.  ResNet50V2's 56x56 output leaves ragged 16x16 tiles on
+    the bottom and right edges (masked pixels); the batches are odd so the last persistent round is partial."""
+    import torch
+    from deep_insight_face.networks.triplet import DifEmbedder
+    rng = np.random.default_rng(33)
+    cases = [('resnet', 'v2', 512, (112, 112, 3), 37), ('iresnet50', 'v2', 512, (112, 112, 3), 19),
+             ('yolov3', 'v3', 1, (416, 416, 3), 2)]
+    for arch, head, emd, shape, n in cases:
+        x = torch.from_numpy(rng.integers(0, 256, (n,) + shape, dtype=np.uint8)).cuda()
+        m = DifEmbedder(arch, head, emd, shape, max_batch=n).init_synthetic(7)
+        m.set_input_transform(scale=1 / 255.)
+        a = m.embed(x)
+        names = [k for _, k, _ in m.op_table()]
+        assert any(k.startswith('stem') for k in names), names
+        a2 = m.embed(x)
+        m.set_option('stem', 0)
+        assert not any(k.startswith('stem') for _, k, _ in m.op_table())
+        b = m.embed(x)
+        m.set_option('stem', 1)
+        a, a2, b = [t if isinstance(t, list) else [t] for t in (a, a2, b)]
+        for ta, ta2, tb in zip(a, a2, b):
+            assert torch.equal(ta, ta2)
+            scale = float(tb.abs().max())
+            assert float((ta - tb).abs().max()) <= 2e-5 * max(scale, 1.0), arch                # YOLOv3: 75 layers deep
+        m.close()
+
+
 def test_streamk_fallback_branch(cuda, monkeypatch):
     """The stream-K owner normally adds its partners' partial slabs; if a partner is not
     co-resident it recomputes the missing K range itself.  That branch is rare and

@@ -93,7 +93,7 @@ def test_yolov3_face_cfg_layer_by_layer(structure):
     net = yolo_v3_face(1, 416)
     lib = dict(net.param_spec())
     assert lib == dict(odet.yolov3_spec(1))
-    macs = {name: m for name, kern, m in net.op_table() if kern.startswith(('conv_igemm', 'stem3x3'))}
+    macs = {name: m for name, kern, m in net.op_table() if kern.startswith(('conv_igemm', 'stem'))}
     assert len(macs) == 75
     for i, c in enumerate(convs):
         assert lib['conv_%d/kernel' % i] == (c['k'], c['k'], c['cin'], c['cout']), i
