@@ -1039,13 +1039,19 @@ int Net::finalize(int mb) {
   sk_max_blocks = conv_max_blocks();
   if (const char* e = getenv("DIF_SK_SPIN_LIMIT")) sk_spin_limit = atoi(e);   // test hook (tests/test_embed_gpu.py)
   if (const char* e = getenv("DIF_PIPE")) use_pipe = atoi(e) != 0;              // read once here, never per launch
-  // Two lanes pay off when the kernels are long enough for one lane's tail to hide under the other
-  // lane's head (IResNet-100 at batch 256: +4 %); with many short launches (ResNet50V2: -1 %) the
-  // half-size launches only fill the chip worse.  Default: two lanes from 10 GFLOP per launch per lane.
+  // Lanes: the batch is cut into nl parts that run the launch list on nl streams.
+  //  * long launches (IResNet-100 at batch 256: 12 GFLOP per launch per lane): two lanes, each launch sized for the
+  //    whole chip -- one lane's tail hides under the other lane's head (+4 %);
+  //  * short launches (ResNet50V2: 0.1 ms each, a third of it ramp and a ragged last round of tiles): two lanes whose
+  //    persistent grids take HALF the chip's resident slots each, so both lanes' kernels are co-resident all the time
+  //    and either one's ramp, tail and epilogue bursts leave the matrix pipes to the other (+3..5 % at batch 128-256;
+  //    with whole-chip grids the second lane's blocks only queue behind the first's: -1 %).
   int n_conv = 0;
   for (const Op& op : ops) n_conv += op.kind == OP_CONV;
   const double per_launch = flops_per_image() * (max_batch / 2) / (n_conv > 0 ? n_conv : 1);
-  int nl = getenv("DIF_STREAMS") ? atoi(getenv("DIF_STREAMS")) : (per_launch >= 10e9 ? 2 : 1);
+  const bool long_launches = per_launch >= 10e9;
+  int nl = getenv("DIF_STREAMS") ? atoi(getenv("DIF_STREAMS")) : 2;
+  const int lane_split = getenv("DIF_SK_LANE_SPLIT") ? atoi(getenv("DIF_SK_LANE_SPLIT")) : (long_launches ? 0 : 1);
   if (nl < 1) nl = 1;
   if (nl > 8) nl = 8;
   if (max_batch < 64 * nl || !extra_outputs.empty()) nl = 1;
@@ -1069,7 +1075,6 @@ int Net::finalize(int mb) {
     L.sk_epoch = 0;
     // persistent-grid size of this lane's stream-K launches.  DIF_SK_LANE_SPLIT=1 gives each lane 1/nl of the
     // chip's resident slots, so the lanes' grids are co-resident instead of queueing behind each other
-    static const int lane_split = getenv("DIF_SK_LANE_SPLIT") ? atoi(getenv("DIF_SK_LANE_SPLIT")) : 0;
     L.sk_max_blocks = (lane_split && nl > 1) ? sk_max_blocks / nl : sk_max_blocks;
 
     L.bufs.assign(buf_elems.size(), nullptr);
@@ -1194,7 +1199,7 @@ int Net::run_op(const Op& op, Lane& L, const void* xin, int n, int layout, int d
       }
       a.sk_slab = L.sk_slab;
       a.sk_flag = L.sk_flag;
-      a.sk_max_blocks = L.sk_max_blocks;
+      a.sk_max_blocks = lanes_active ? L.sk_max_blocks : sk_max_blocks;   // one lane alone takes the whole chip
       a.sk_epoch = ++L.sk_epoch;
       a.sk_spin_limit = sk_spin_limit;
       a.use_pipe = use_pipe;
@@ -1320,7 +1325,8 @@ int Net::embed(const void* xin, int n, int layout, int dtype, float* out, hipStr
   if (dtype != DIF_DTYPE_F32 && dtype != DIF_DTYPE_U8) return set_error("dif_net_embed: bad dtype %d", dtype);
 
   const int nl = (int)lanes.size();
-  if (op_ms || nl == 1 || n < 64) {
+  lanes_active = !(op_ms || nl == 1 || n < 64);
+  if (!lanes_active) {
     std::vector<hipEvent_t> ev;
     if (op_ms) {
       ev.resize(ops.size() + 1);

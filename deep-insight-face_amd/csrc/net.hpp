@@ -123,6 +123,7 @@ struct Net {
   };
   std::vector<Lane> lanes;
   hipEvent_t ev_start = nullptr;
+  bool lanes_active = false;        // this forward runs on all lanes (each with its share of the resident slots)
   std::vector<int64_t> buf_elems;   // per image
   int sk_max_blocks = 0;
   int sk_spin_limit = 1 << 18;

@@ -339,7 +339,7 @@ def test_embed_full_batch_properties(cuda):
 
 
 @pytest.mark.parametrize('arch,head,emd,n', [('iresnet50', 'v2', 512, 96), ('iresnet100', 'v2', 512, 64),
-                                             ('resnet', 'v2', 512, 200), ('resnet', 'v1', 128, 200),
+                                             ('resnet', 'v2', 512, 512), ('resnet', 'v1', 128, 512),
                                              ('vgg16', 'v2', 512, 16)])
 def test_embed_bf16x3_mode_vs_oracle(cuda, arch, head, emd, n):
     """The split-bf16 throughput mode (dif_net_set_option "bf16x3": three bf16 terms per f32 operand, six MFMA
