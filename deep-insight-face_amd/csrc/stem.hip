@@ -6,11 +6,11 @@
 //
 // As an implicit GEMM on the general kernel (conv.hip) these layers pad every tap to four channels and K to a
 // multiple of 32 (36 -> 64: 58 % of the MFMA work wasted; 196 -> 224: 34 %) and gather 16-byte pieces per tap.
-// Here K is the true 3 * KH * KW (padded to the MFMA's k = 2), a block owns a TH x 16 tile of OUTPUT pixels of one
-// image, its input patch ((TH-1)*S + KH rows x 15*S + KW columns x 3 channel planes) sits in LDS, and an operand
+// Here K is the true 3 * KH * KW (padded to the MFMA's k = 2), a block owns a TH x TW tile of OUTPUT pixels of one
+// image, its input patch ((TH-1)*S + KH rows x (TW-1)*S + KW columns x 3 channel planes) sits in LDS, and an operand
 // element of (pixel, k) is one ds_read_b32 at  lane_base(pixel) + offset(k):  the im2col matrix is never formed.
 //
-// MFMA rows = 32 pixels of the wave (2 rows x 16 columns of the tile), columns = output channels (weights from LDS,
+// MFMA rows = 32 pixels of the wave (2 rows x 16 columns of the tile, or 4 x 8), columns = output channels (weights from LDS,
 // [k][64]).  A lane then holds ONE channel (two: p and 32 + p) of 16 pixels: its epilogue constants are six
 // registers per tile, and each accumulator register is stored as it stands -- 32 consecutive channels of two
 // pixels per instruction, two 128-byte segments, the full-rate store shape (16-byte pieces of 64 different rows,
@@ -28,11 +28,16 @@ namespace dif {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int KH_, int KW_, int S_, int PAD_, int WAVES_>
+// WR x WC = 32: the pixels of one wave (rows x columns); BR x BC waves make the block's tile.  Tiles that do not divide
+// the map compute masked pixels, so the shapes follow the maps: 2x16 pixels, 4x1 waves = 8x16 tiles for IResNet's
+// 112x112 output; 4x8 pixels, 1x7 waves = 4x56 tiles for ResNet50V2's 56x56 (16x16 tiles wasted 30 % of the MFMA work).
+template <int KH_, int KW_, int S_, int PAD_, int WR_, int WC_, int BR_, int BC_>
 struct StemCfg {
-  static constexpr int KH = KH_, KW = KW_, S = S_, PAD = PAD_, WAVES = WAVES_;
+  static constexpr int KH = KH_, KW = KW_, S = S_, PAD = PAD_, WR = WR_, WC = WC_, BR = BR_, BC = BC_;
+  static_assert(WR * WC == 32 && WC >= 8 && WR % 2 == 0, "a wave owns 32 pixels; 4h + i stays inside a row; even tile origins");
+  static constexpr int WAVES = BR * BC;
   static constexpr int NT = 64 * WAVES;
-  static constexpr int TH = 2 * WAVES, TW = 16;            // output tile of a block
+  static constexpr int TH = WR * BR, TW = WC * BC;         // output tile of a block
   static constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW;
   static constexpr int PWP = PW | 1;                       // odd row pitch
   static constexpr int PP = PH * PWP;                      // floats per channel plane
@@ -74,7 +79,8 @@ __global__ __launch_bounds__(C::NT, 4) void stem_mfma_kernel(const StemArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < C::W_FLOATS; i += C::NT) wts[i] = i < C::K * 64 ? a.w[i] : 0.f;
   const int p = lane & 31, h = lane >> 5;
-  const int ty = 2 * wave + (p >> 4), tx = p & 15;        // this lane's output pixel inside the tile
+  const int wave_r = wave / C::BC, wave_c = wave - wave_r * C::BC;
+  const int ty = wave_r * C::WR + p / C::WC, tx = wave_c * C::WC + p % C::WC;   // this lane's output pixel inside the tile
   const int lane_base = ty * C::S * C::PWP + tx * C::S;
   // k = 2j + h: offset(2j + 1) - offset(2j) takes three values (next channel / next tap / next kernel row)
   const int base_c = lane_base + h * C::PP;
@@ -159,10 +165,11 @@ __global__ __launch_bounds__(C::NT, 4) void stem_mfma_kernel(const StemArgs a) {
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a0, acc0, 0, 0, 0);    // rows = the wave's 32 pixels, columns = channels
       acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a1, acc1, 0, 0, 0);
     }
-    // epilogue in the accumulator layout: acc_t[4q + i] = channel 32t + p of the wave's pixel 8q + 4h + i, i.e. tile
-    // row 2 wave + q / 2, column 8 (q & 1) + 4h + i.  One register of the accumulator is stored by one instruction:
-    // 32 consecutive channels of two pixels = two 128-byte segments (MI355X_MICROARCH.md: the full-rate shape).
-    const int ho0 = th0w + 2 * wave, wo0 = tw0w + 4 * h;
+    // epilogue in the accumulator layout: acc_t[4q + i] = channel 32t + p of the wave's pixel 8q + 4h + i, i.e. row
+    // (8q + i) / WC, column (8q + i) % WC + 4h of the wave's pixels.  One register of the accumulator is stored by
+    // one instruction: 32 consecutive channels of two pixels = two 128-byte segments (MI355X_MICROARCH.md: the
+    // full-rate shape).
+    const int ho0 = th0w + wave_r * C::WR, wo0 = tw0w + wave_c * C::WC + 4 * h;
     const int64_t o0 = (((int64_t)n * a.Ho + ho0) * a.Wo + wo0) * 64 + p;
     const int64_t oy0 = a.y_sub ? (((int64_t)n * ((a.Ho + 1) >> 1) + (ho0 >> 1)) * ((a.Wo + 1) >> 1) + (wo0 >> 1)) * 64 + p : o0;
 #pragma unroll
@@ -171,15 +178,15 @@ __global__ __launch_bounds__(C::NT, 4) void stem_mfma_kernel(const StemArgs a) {
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int dy = q >> 1, dx = 8 * (q & 1) + i;
+          const int dy = (8 * q + i) / C::WC, dx = (8 * q + i) % C::WC;
           if (ho0 + dy < a.Ho && wo0 + dx < a.Wo) {
             const float s = t == 0 ? acc0[4 * q + i] : acc1[4 * q + i];
             const float v = stem_act(fmaf(s, sc[t], sh[t]), a.act, al[t]);
             if (a.y) {
               if (!a.y_sub)
                 a.y[o0 + ((int64_t)dy * a.Wo + dx) * 64 + 32 * t] = v;
-              else if (dy == 0 && (i & 1) == 0)                 // tiles start on even rows and columns
-                a.y[oy0 + (dx >> 1) * 64 + 32 * t] = v;
+              else if ((dy & 1) == 0 && (dx & 1) == 0)          // tiles and waves start on even rows and columns
+                a.y[oy0 + ((int64_t)(dy >> 1) * ((a.Wo + 1) >> 1) + (dx >> 1)) * 64 + 32 * t] = v;
             }
             if (a.y2) a.y2[o0 + ((int64_t)dy * a.Wo + dx) * 64 + 32 * t] = stem_act(fmaf(v, sc2[t], sh2[t]), a.act2, al2[t]);
           }
@@ -250,8 +257,8 @@ int stem_mfma_run(const float* x, const float* w_hwio, const float* scale, const
   a.act2 = act2;
   a.y_sub = y_sub;
   a.tiles_h = a.tiles_w = a.tiles = 0;
-  if (KH == 3 && stride == 1) return stem_launch<StemCfg<3, 3, 1, 1, 4>>(a, st);
-  if (KH == 7 && stride == 2) return stem_launch<StemCfg<7, 7, 2, 3, 8>>(a, st);
+  if (KH == 3 && stride == 1) return stem_launch<StemCfg<3, 3, 1, 1, 2, 16, 4, 1>>(a, st);
+  if (KH == 7 && stride == 2) return stem_launch<StemCfg<7, 7, 2, 3, 4, 8, 1, 7>>(a, st);
   return set_error("stem: no kernel for a %dx%d / stride %d first layer", KH, KH, stride);
 }
 

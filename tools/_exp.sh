@@ -1,2 +1,3 @@
-mkdir -p gpurun_out/r3b
-(timeout -k 10 700 python -m pytest tests -m gpu -q -x > gpurun_out/r3b/tests.log 2>&1; echo "rc=$?" >> gpurun_out/r3b/tests.log); tail -3 gpurun_out/r3b/tests.log
+timeout -k 10 300 python -m pytest tests/test_embed_gpu.py -m gpu -q -x -k "stem or vs_oracle or full_batch" 2>&1 | tail -2
+timeout -k 10 100 python tools/layer_profile.py resnet 256 2>&1 | grep -E "^conv1_conv|TOTAL"
+timeout -k 10 100 python tools/layer_profile.py iresnet100 256 2>&1 | grep -E "^conv1 |TOTAL"
