@@ -576,7 +576,9 @@ struct EpiRes {
 // PRELOAD = false (the patch path, which never prefetches the shortcut tile: its registers hold the next patch): the
 // shortcut is fetched row by row inside the loop instead of all at once -- that kernel then compiles without spills.
 // TILE2D (AM = 6): tile row r is output pixel (h0 + r / 8, w0 + r % 8) of one image instead of pixel m0 + r.
-template <class T, bool PRELOAD = true, bool TILE2D = false>
+// YSUB = false (the split-bf16 kernels, whose register budget is spent): ConvArgs::y_sub is not honoured (conv_run keeps
+// such layers on the f32 kernels).
+template <class T, bool PRELOAD = true, bool TILE2D = false, bool YSUB = true>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T::WM][T::WN], int m0, int n0,
                                               float* smem, EpiRes<T>& er, bool res_loaded) {
   constexpr int WM = T::WM, WN = T::WN;
@@ -652,7 +654,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
         }
         int64_t oy = o;
         bool y_on = a.y != nullptr;
-        if (a.y_sub) {
+        if (YSUB && a.y_sub) {
           int img, rr, ho, wo;
           a.fd_howo.divmod(row, img, rr);
           a.fd_wo.divmod(rr, ho, wo);
@@ -874,7 +876,7 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const 
         kdone = q_ke;
       }
       if (a.trace) tC = __builtin_amdgcn_s_memrealtime();
-      conv_epilogue<T, !PATCH, AM == 6>(a, acc, m0, n0, smem, er, whole);
+      conv_epilogue<T, !PATCH, AM == 6, !BF3>(a, acc, m0, n0, smem, er, whole);
     }
     if (a.trace) {
       const unsigned long long tD = __builtin_amdgcn_s_memrealtime();
@@ -1359,7 +1361,7 @@ int conv_run(const ConvArgs& a, hipStream_t st) {
     if (span * a.H * a.W * a.Cin * 4 >= 0x7fffffffLL)
       return set_error("conv: a 256-pixel tile spans more than 2 GiB of input (%dx%dx%d)", a.H, a.W, a.Cin);
   }
-  if (a.w3 && bf3_pays(a)) {
+  if (a.w3 && bf3_pays(a) && !a.y_sub) {
     // split-bf16 mode (8 waves, 128x128; 256x64 for narrow layers): stream-K / one tile per block as for f32
     const bool pw = a.KH == 1 && a.KW == 1 && a.pad_t == 0 && a.pad_l == 0 && a.Cin % BK == 0;
     if (a.Cout <= 64) {
