@@ -411,6 +411,16 @@ def main():
         b256_ms = float(np.mean([a.elapsed_time(b) for a, b in e256]))
 
     if rank == 0:
+        # the shader clock THIS box holds under back-to-back f32 MFMAs (boxes of the pool differ by a few percent)
+        import ctypes
+        from deep_insight_face import _native as N
+        ghz, probe_tf = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        N.check(N.lib.dif_probe_mfma_clock(ctypes.byref(ghz), ctypes.byref(probe_tf), torch.cuda.current_stream().cuda_stream))
+        conv_ghz = None
+        if pipe is None:
+            for _ in range(max(3, min(args.steps, 10))):      # the governor settles over tens of ms: measure under the steps' load
+                model.embed(crops)
+            conv_ghz = model.held_clock_ghz(crops)            # inside the conv kernels of one (single-lane) forward
         flops_embed = model.flops_per_image * batch            # algorithmic: 2 * MACs of every conv/dense
         if pipe is not None:
             flops_embed += det.flops_per_image * batch
@@ -449,8 +459,12 @@ def main():
                 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': measured_traffic(args.workload, batch),
                 'traffic_unit': 'HBM bytes per forward (rocprofv3 PMC, profiles/)',
-                'clock_note': 'peak is the 2.4 GHz figure; s_memtime/s_memrealtime inside these kernels shows the chip '
-                              'holding 2.03 GHz under this load (profiles/r01_conv_trace.txt), i.e. 133 TFLOP/s',
+                'clock_note': 'peak is the 2.4 GHz figure.  conv_clock_ghz = shader clock held INSIDE the convolution kernels of one '
+                              'single-lane forward on this box (s_memtime / s_memrealtime over every block: dif_net_embed_clock); '
+                              'mfma_loop_clock_ghz / mfma_loop_tflops = what a register-only loop of the same MFMA instruction '
+                              'holds and sustains on this box (dif_probe_mfma_clock)',
+                'conv_clock_ghz': conv_ghz, 'mfma_loop_clock_ghz': ghz.value, 'mfma_loop_tflops': probe_tf.value,
+                'frac_of_peak_at_conv_clock': achieved / (PEAK_F32_MFMA_TFLOPS * conv_ghz / 2.4) if conv_ghz else None,
                 'algorithmic_flops_per_forward': flops_embed,
                 'forward_ms_hip_events': embed_ms,
                 'conv_only': {'ms': conv_ms, 'tflops': conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms else None},

@@ -524,6 +524,86 @@ __device__ __forceinline__ void gemm_mainloop_patch(const PA& pa, BLoader& bl, i
   __syncthreads();
 }
 
+// ------------------------------------------------------------------------------------------
+// Patch mainloop with the B operand straight from L2 into the MFMA registers ("B-direct", AM = 13 / 15 / 16).
+//
+// In gemm_mainloop_patch the weights still go global -> registers -> LDS -> registers every K-step, and that LDS
+// round trip is what ties a block's four waves to one barrier per K-step (the K-loop ablation of round 1: barrier,
+// staging writes and fragment reads cost 7-11 points each).  The weight matrix is launch-invariant, so net.hip lays
+// it out once in FRAGMENT order (ConvArgs::w_frag): for a 32-column tile and a K-step, the four 16-byte pieces a
+// lane feeds to the 16 MFMAs are four contiguous KB, lane l at byte 16 l -- a wave fetches its B fragments with four
+// fully coalesced buffer_load_dwordx4, half a K-step (eight MFMAs) ahead, into registers that go to the MFMAs as they
+// are (a whole step ahead costs 16 more registers: 120 spilled).  LDS then
+// holds the A patch only, and the block synchronises only when the patch is replaced: two barriers per NINE K-steps
+// instead of ten.  (Both waves of a column pair fetch the same KB: the second hits L1/L2; 16 KB per block per step.)
+template <class T, class PA, class Tail>
+__device__ __forceinline__ void gemm_mainloop_patch_bd(const PA& pa, const ConvArgs& a, int n0, int kbeg, int kend,
+                                                       float* lds, f32x16 (&acc)[1][1], Tail&& tail) {
+  static_assert(T::BM == 64 && T::BN == 64 && T::NT == 256, "patch path: 64x64 tile");
+  float* patch = lds;
+  const int lane = threadIdx.x & 63;
+  const int h = lane >> 5;
+  const int KS = a.Kpad / BK;
+  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.w_frag, a.w_frag_bytes);
+  // byte offset of this lane's piece (s, u) = q of K-step ks:  ((tile * KS + ks) * 4 + q) * 1024 + 16 lane
+  // (a column tile past ceil(Cout / 32) lies beyond the descriptor: reads zero)
+  const uint32_t lane_off = (uint32_t)((n0 >> 5) + T::wave_col()) * (uint32_t)KS * 4096u + (uint32_t)lane * 16u;
+  // half a K-step (s = 0 or 1: sixteen k, eight MFMAs) of fragments: pieces (s, 0) and (s, 1)
+  auto bload = [&](int ks, int s, f32x4 (&b)[2]) {
+    const uint32_t vo = lane_off + (uint32_t)ks * 4096u + (uint32_t)s * 2048u;
+    b[0] = buf_load4(wrs, vo);
+    b[1] = buf_load4(wrs, vo + 1024u);
+  };
+
+  f32x4 pr[PA::NPC], bA[2], bB[2];                         // bA: half s = 0 of the coming step, bB: half s = 1
+  int cb = kbeg / 9, tap = kbeg - cb * 9;
+  pa.load(cb, pr);
+  bload(kbeg, 0, bA);
+  pa.store(patch, pr);
+  __syncthreads();
+  bool pf_issued = false;
+  // one half-step: eight MFMAs on the A fragments of half s (read from the patch here) and the B fragments in b
+  auto half = [&](int s, const f32x4 (&b)[2]) {
+    const int kh = tap >= 6 ? 2 : (tap >= 3 ? 1 : 0);
+    const int e = pa.base[0] + kh * pa.WP + (tap - 3 * kh);
+    const int sa = patch_swz(e);
+    const float* pae = patch + e * 32;
+    const int l0 = 2 * h + 4 * s;                          // logical chunks l0, l0 + 1 (k = 16 s + 8 h .. + 7)
+    const f32x4 fa0 = *reinterpret_cast<const f32x4*>(pae + ((l0 ^ sa) << 2));
+    const f32x4 fa1 = *reinterpret_cast<const f32x4*>(pae + (((l0 + 1) ^ sa) << 2));
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[t], b[0][t], acc[0][0], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[t], b[1][t], acc[0][0], 0, 0, 0);
+  };
+  int ks = kbeg;
+  for (; ks + 1 < kend; ++ks) {
+    bload(ks, 1, bB);                                      // lands under the first half's MFMAs
+    if (!pf_issued && tap >= PATCH_PF_TAP && (cb + 1) * 9 < kend) {
+      pa.load(cb + 1, pr);                                 // the next slice's patch: lands while taps PF_TAP .. 8 run
+      pf_issued = true;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    half(0, bA);
+    bload(ks + 1, 0, bA);                                  // lands under the second half's MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+    half(1, bB);
+    if (++tap == 9) {
+      tap = 0;
+      ++cb;
+      __syncthreads();                                     // every wave has read its last fragment of the old patch
+      pa.store(patch, pr);
+      pf_issued = false;
+      __syncthreads();
+    }
+  }
+  bload(ks, 1, bB);
+  tail();
+  half(0, bA);
+  half(1, bB);
+  __syncthreads();
+}
+
 __device__ __forceinline__ float apply_act(float v, int act, float alpha) {
   if (act == ACT_RELU) return fmaxf(v, 0.f);
   if (act == ACT_PRELU) return v >= 0.f ? v : v * alpha;
@@ -694,8 +774,10 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const 
   static_assert(!(PRE && DMA), "pre-activation needs register staging");
   static_assert(!(AM != 0 && DMA), "the specialised loaders are register-staged");
   static_assert(!(BF3 && DMA), "the split-bf16 mainloop stages through registers");
-  static_assert((AM != 3 && AM != 5 && AM != 6) || (!PRE && !DMA && !BF3 && T::BM == 64 && T::BN == 64), "patch path: plain f32, 64x64 tile");
-  constexpr bool PATCH = (AM == 3 || AM == 5 || AM == 6);
+  constexpr int AMP = AM % 10;                              // AM >= 10: the B-direct form of patch path AM - 10
+  constexpr bool PATCH = (AMP == 3 || AMP == 5 || AMP == 6), BD = AM >= 10;
+  static_assert(!BD || PATCH, "B-direct exists for the patch paths only");
+  static_assert(!PATCH || (!PRE && !DMA && !BF3 && T::BM == 64 && T::BN == 64), "patch path: plain f32, 64x64 tile");
   constexpr int WM = T::WM, WN = T::WN;
   constexpr int SLAB = T::BM * T::BN;    // floats per partial-accumulator slab
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -746,9 +828,9 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const 
     using ALoadReg = typename std::conditional<AM == 1, ConvPwLoader<T::NA, T::RP, PRE>,
                                                ConvALoader<T::NA, T::RP, PRE, AM == 2 ? 2 : 0>>::type;
     using ALoadGather = typename std::conditional<DMA, ConvADmaLoader<T::NA, T::RP>, ALoadReg>::type;
-    using ALoadLin = typename std::conditional<AM == 3, PatchA<T, PATCH_EMAX_S>,                  // AM 3 / 5 / 6: halo-resident patch
-                                               typename std::conditional<AM == 5, PatchA<T, PATCH_EMAX_L>, ALoadGather>::type>::type;
-    using ALoad = typename std::conditional<AM == 6, PatchA2D<T>, ALoadLin>::type;
+    using ALoadLin = typename std::conditional<AMP == 3, PatchA<T, PATCH_EMAX_S>,                 // AM 3 / 5 / 6: halo-resident patch
+                                               typename std::conditional<AMP == 5, PatchA<T, PATCH_EMAX_L>, ALoadGather>::type>::type;
+    using ALoad = typename std::conditional<AMP == 6, PatchA2D<T>, ALoadLin>::type;
     using BLoadF32 = typename std::conditional<DMA, DmaRowLoader<T::NB, T::RP>, RowLoader<T::NB, T::RP>>::type;
     using BLoad = typename std::conditional<BF3, Bf3WeightLoader<T>, BLoadF32>::type;
     ALoad al(a, m0);
@@ -765,6 +847,10 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const 
     auto run = [&](int k0, int k1, bool prefetch_res) {
       if constexpr (BF3)
         gemm_mainloop_bf3<T>(al, bl, k0, k1, reinterpret_cast<char*>(smem), acc, [&] {
+          if (prefetch_res && a.res) er.load(a, m0, n0);
+        });
+      else if constexpr (BD)
+        gemm_mainloop_patch_bd<T>(al, a, n0, k0, k1, smem, acc, [&] {
           if (prefetch_res && a.res) er.load(a, m0, n0);
         });
       else if constexpr (PATCH)
@@ -876,7 +962,7 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const 
         kdone = q_ke;
       }
       if (a.trace) tC = __builtin_amdgcn_s_memrealtime();
-      conv_epilogue<T, !PATCH, AM == 6, !BF3>(a, acc, m0, n0, smem, er, whole);
+      conv_epilogue<T, !PATCH, AMP == 6, !BF3>(a, acc, m0, n0, smem, er, whole);
     }
     if (a.trace) {
       const unsigned long long tD = __builtin_amdgcn_s_memrealtime();
@@ -993,6 +1079,7 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_pipe_kernel(const C
 
   unsigned long long tr_setup = 0, tr_pro = 0, tr_steps = 0, tr_hand = 0, tr_n = 0;
   const unsigned long long tr_t0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long tr_c0 = a.trace ? __builtin_amdgcn_s_memtime() : 0;
   while (true) {
     const unsigned long long tA = a.trace ? __builtin_amdgcn_s_memrealtime() : 0;
     int mt, nt;
@@ -1109,7 +1196,7 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_pipe_kernel(const C
     unsigned long long* t = a.trace + (size_t)blockIdx.x * 8;
     t[0] = tr_setup; t[1] = tr_pro; t[2] = tr_steps; t[3] = tr_hand; t[4] = tr_n; t[5] = tr_t0;
     t[6] = __builtin_amdgcn_s_memrealtime();
-    t[7] = 2;
+    t[7] = 2 | ((__builtin_amdgcn_s_memtime() - tr_c0) << 8);
   }
   // drain: the last tile has no successor to hide behind
   epi_pre(std::integral_constant<int, 0>()); epi_post(std::integral_constant<int, 0>());
@@ -1248,7 +1335,10 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
     if (slots > a.sk_max_blocks) slots = a.sk_max_blocks;
     // DIF_PATCH2D_FIRST=0: the pipelined kernel keeps the short-K 3x3 layers (64 input channels) it took before
     static const bool p2d_first = !(getenv("DIF_PATCH2D_FIRST") && !atoi(getenv("DIF_PATCH2D_FIRST")));
-    if (!use_dma && p2d_first && patch2d_applies(a)) return launch_conv_pre<T, false, false, 6>(a, st);
+    static const bool use_bd = !(getenv("DIF_NO_BD") && atoi(getenv("DIF_NO_BD")));
+    const bool bd = use_bd && a.w_frag != nullptr;
+    if (!use_dma && p2d_first && patch2d_applies(a))
+      return bd ? launch_conv_pre<T, false, false, 16>(a, st) : launch_conv_pre<T, false, false, 6>(a, st);
     if (!use_dma && a.Cin % 4 == 0 && pipe_applies(a, tiles, a.Kpad / BK, slots)) {
       // pointwise layers retire the previous tile four chunks per K-step, i.e. within the first two
       // steps (measured best for every K: 2 steps +16 %, 8 steps +5 % over one chunk per step); the
@@ -1262,10 +1352,12 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
   if (pw) return launch_conv_pre<T, false, false, 1>(a, st);
   if constexpr (kDefaultTile) {
     if (!use_dma) {
+      static const bool use_bd2 = !(getenv("DIF_NO_BD") && atoi(getenv("DIF_NO_BD")));
+      const bool bd2 = use_bd2 && a.w_frag != nullptr;
       const int emax = patch_applies(a);
-      if (emax == PATCH_EMAX_S) return launch_conv_pre<T, false, false, 3>(a, st);
-      if (emax == PATCH_EMAX_L) return launch_conv_pre<T, false, false, 5>(a, st);
-      if (patch2d_applies(a)) return launch_conv_pre<T, false, false, 6>(a, st);
+      if (emax == PATCH_EMAX_S) return bd2 ? launch_conv_pre<T, false, false, 13>(a, st) : launch_conv_pre<T, false, false, 3>(a, st);
+      if (emax == PATCH_EMAX_L) return bd2 ? launch_conv_pre<T, false, false, 15>(a, st) : launch_conv_pre<T, false, false, 5>(a, st);
+      if (patch2d_applies(a)) return bd2 ? launch_conv_pre<T, false, false, 16>(a, st) : launch_conv_pre<T, false, false, 6>(a, st);
     }
   }
   if (a.pre_scale) return launch_conv_pre<T, true, false, 0>(a, st);
@@ -1276,9 +1368,13 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
 template <class T, bool PRE, bool DMA, int AM, bool BF3>
 static int launch_conv_pre(const ConvArgs& a, hipStream_t st) {
   auto kern = conv_igemm_kernel<T, PRE, DMA, AM, BF3>;
+  constexpr int AMP = AM % 10;
+  constexpr int emax = AMP == 3 ? PATCH_EMAX_S : (AMP == 5 ? PATCH_EMAX_L : 100);
+  constexpr int epi_bytes = T::BM * (T::BN + 4) * 4;       // the epilogue's staging tile
+  // B-direct: the patch alone (or the epilogue's staging tile if that is larger)
+  constexpr int bd_bytes = emax * 128 > epi_bytes ? emax * 128 : epi_bytes;
   constexpr int lds_bytes = BF3 ? Bf3<T>::LDS_BYTES
-                                : (AM == 3 ? patch_lds_bytes(PATCH_EMAX_S)
-                                           : (AM == 5 ? patch_lds_bytes(PATCH_EMAX_L) : (AM == 6 ? patch_lds_bytes(100) : T::LDS_BYTES)));
+                                : (AM >= 10 ? bd_bytes : ((AMP == 3 || AMP == 5 || AMP == 6) ? patch_lds_bytes(emax) : T::LDS_BYTES));
   if (allow_dynamic_lds(kern, lds_bytes)) return -1;
   const int64_t tiles = ((a.M + T::BM - 1) / T::BM) * (int64_t)((a.Cout + T::BN - 1) / T::BN);
   const int KS = a.Kpad / BK;

@@ -913,6 +913,30 @@ int Net::finalize(int mb) {
         if (upload(this, params[op.w].data, &op.d_w_raw)) return -1;
         op.stem_mfma = true;
       }
+      // fragment-order copy for the B-direct patch mainloop (conv.hip: gemm_mainloop_patch_bd): every layer the patch paths
+      // can take (3x3 / stride 1 / pad 1, whole 32-channel slices)
+      op.d_w_frag = nullptr;
+      op.w_frag_bytes = 0;
+      if (!compute_bf16x3 && op.k_order == 1 && op.KH == 3 && op.KW == 3 && op.stride == 1 && op.pad_t == 1 && op.pad_l == 1 &&
+          !op.pre_bn.valid()) {
+        const int KS = op.Kpad / BK, NT32 = (op.Cout + 31) / 32;
+        std::vector<float> frag((size_t)NT32 * 32 * op.Kpad, 0.f);
+        size_t o = 0;
+        for (int nt = 0; nt < NT32; ++nt)
+          for (int ks = 0; ks < KS; ++ks)
+            for (int s2 = 0; s2 < 2; ++s2)
+              for (int u = 0; u < 2; ++u)
+                for (int hh = 0; hh < 2; ++hh)
+                  for (int nn = 0; nn < 32; ++nn)
+                    for (int t = 0; t < 4; ++t, ++o) {
+                      const int row = nt * 32 + nn;
+                      if (row < op.Cout) frag[o] = packed[(size_t)row * op.Kpad + (size_t)ks * BK + 16 * s2 + 8 * hh + 4 * u + t];
+                    }
+        if ((uint64_t)frag.size() * 4 < 0xFFFFFFF0ull) {
+          if (upload(this, frag, &op.d_w_frag)) return -1;
+          op.w_frag_bytes = (uint32_t)(frag.size() * 4);
+        }
+      }
       op.d_w3 = nullptr;
       if (compute_bf16x3 && op.Cin % BK == 0 && op.Cout >= 32 && op.Cout % 4 == 0) {
         // split-bf16 mode: hi / mid / lo planes by repeated round-to-nearest-even, [Cout][Kpad/32][3][32]
@@ -1140,6 +1164,8 @@ int Net::run_op(const Op& op, Lane& L, const void* xin, int n, int layout, int d
       a.x = ptr(op.x);
       a.w = op.d_w;
       a.w3 = op.d_w3;
+      a.w_frag = op.d_w_frag;
+      a.w_frag_bytes = op.w_frag_bytes;
       a.y = ptr(op.y);
       a.y2 = ptr(op.y2);
       a.scale = op.d_scale;
@@ -1203,6 +1229,7 @@ int Net::run_op(const Op& op, Lane& L, const void* xin, int n, int layout, int d
       a.sk_epoch = ++L.sk_epoch;
       a.sk_spin_limit = sk_spin_limit;
       a.use_pipe = use_pipe;
+      a.trace = trace_buf ? trace_buf + trace_off[&op - ops.data()] * 8 : nullptr;
       if (op.d_w_raw && op.stem_mfma && use_stem) {
         if (stem_mfma_run(a.x, op.d_w_raw, a.scale, a.shift, a.alpha, a.scale2, a.shift2, a.alpha2, a.y, a.y2, n, a.H, a.W,
                           a.Ho, a.Wo, a.KH, a.stride, a.act, a.act2, a.y_sub, st))
@@ -1369,6 +1396,52 @@ int Net::embed(const void* xin, int n, int layout, int dtype, float* out, hipStr
     DIF_HIP(hipEventRecord(lanes[l].done, lanes[l].stream));
     DIF_HIP(hipStreamWaitEvent(st, lanes[l].done, 0));
   }
+  return 0;
+}
+
+// The shader clock held INSIDE the convolution kernels of one forward (single lane): every block of every conv launch
+// records its life in shader cycles (s_memtime) and in 100 MHz ticks (s_memrealtime); the ratio of the sums is the
+// life-weighted mean clock.  The rooflines price against the 2.4 GHz peak; this is what the chip sustains under the
+// kernels' own mix of MFMA, LDS and memory instructions (a register-only MFMA loop holds more: dif_probe_mfma_clock).
+int Net::embed_clock(const void* xin, int n, int layout, int dtype, float* out, hipStream_t st, double* ghz) {
+  if (!finalized) return set_error("dif_net_embed_clock: call dif_net_finalize first");
+  if (!ghz) return set_error("dif_net_embed_clock: null output");
+  if (n < 1 || n > max_batch) return set_error("dif_net_embed_clock: batch %d outside [1, max_batch=%d]", n, max_batch);
+  trace_off.assign(ops.size(), 0);
+  size_t total = 0;
+  for (size_t i = 0; i < ops.size(); ++i) {
+    trace_off[i] = total;
+    if (ops[i].kind != OP_CONV) continue;
+    const TensorDesc& yd = tensors[ops[i].y >= 0 && !ops[i].y_sub ? ops[i].y : ops[i].y2];
+    const size_t tiles = (((size_t)n * yd.H * yd.W + 63) / 64) * (((size_t)ops[i].Cout + 63) / 64);
+    total += tiles > (size_t)sk_max_blocks ? tiles : (size_t)sk_max_blocks;     // a launch is one block per tile or a resident grid
+  }
+  unsigned long long* d = nullptr;
+  DIF_HIP(hipMalloc(&d, total * 8 * sizeof(unsigned long long)));
+  DIF_HIP(hipMemsetAsync(d, 0, total * 8 * sizeof(unsigned long long), st));
+  trace_buf = d;
+  int rc = 0;
+  lanes_active = false;
+  for (size_t i = 0; i < ops.size() && !rc; ++i) rc = run_op(ops[i], lanes[0], xin, n, layout, dtype, out, st);
+  trace_buf = nullptr;
+  std::vector<unsigned long long> h;
+  if (!rc) {
+    h.resize(total * 8);
+    if (hipStreamSynchronize(st) != hipSuccess || hipMemcpy(h.data(), d, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
+      rc = set_error("dif_net_embed_clock: reading the records failed");
+  }
+  (void)hipFree(d);
+  if (rc) return rc;
+  double cyc = 0, ticks = 0;
+  for (size_t b = 0; b < total; ++b) {
+    const unsigned long long* t = &h[b * 8];
+    const unsigned kind = (unsigned)(t[7] & 0xff);
+    if ((kind == 1 || kind == 2) && t[6] > t[5]) {
+      cyc += (double)(t[7] >> 8);
+      ticks += (double)(t[6] - t[5]);
+    }
+  }
+  *ghz = ticks > 0 ? cyc / (ticks * 10.0) : 0.0;
   return 0;
 }
 

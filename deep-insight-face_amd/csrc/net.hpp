@@ -67,6 +67,8 @@ struct Op {
   bool stem_mfma = false;     // d_w_raw feeds stem.hip's MFMA kernel (64 filters) instead of elementwise.hip's direct one (32)
   float* d_w_pw = nullptr;
   float* d_w_dense = nullptr;
+  float* d_w_frag = nullptr;  // the matrix in MFMA-fragment order (ConvArgs::w_frag), 3x3 / stride 1 layers on the f32 path
+  uint32_t w_frag_bytes = 0;
   void* d_w3 = nullptr;       // split-bf16 planes of the same matrix (compute mode bf16x3)
   float* d_scale = nullptr;
   float* d_shift = nullptr;
@@ -135,6 +137,10 @@ struct Net {
   int build();                       // dispatch on arch/head
   int finalize(int max_batch);
   int embed(const void* x, int n, int layout, int dtype, float* out, hipStream_t st, float* op_ms = nullptr);
+  // measurement aid (embed_clock): per-op regions of 8 x u64 records per hardware block, written by the conv kernels
+  unsigned long long* trace_buf = nullptr;
+  std::vector<size_t> trace_off;
+  int embed_clock(const void* x, int n, int layout, int dtype, float* out, hipStream_t st, double* ghz);
   int run_op(const Op& op, Lane& L, const void* x, int n, int layout, int dtype, float* out, hipStream_t st);
   const char* kernel_name(const Op& op, int n) const;
   double flops_per_image() const;

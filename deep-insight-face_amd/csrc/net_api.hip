@@ -91,6 +91,12 @@ int dif_net_finalize(dif_net* h, int max_batch) {
   return h->net.finalize(max_batch);
 }
 
+int dif_net_embed_clock(dif_net* h, const void* x_dev, int n, int layout, int dtype, float* out_dev, double* ghz_out,
+                        void* stream) {
+  if (!h) return set_error("dif_net_embed_clock: null handle");
+  return h->net.embed_clock(x_dev, n, layout, dtype, out_dev, static_cast<hipStream_t>(stream), ghz_out);
+}
+
 int dif_net_set_option(dif_net* h, const char* key, int value) {
   if (!h || !key) return set_error("dif_net_set_option: null argument");
   if (!strcmp(key, "pipe")) {

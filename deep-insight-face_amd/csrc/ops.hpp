@@ -41,6 +41,9 @@ inline FastDiv make_fastdiv(int d) {
 struct ConvArgs {
   const float* x;       // [N,H,W,Cin] NHWC
   const float* w;       // packed [Cout][Kpad], zero padded; k order per k_order
+  const float* w_frag;  // the same matrix in MFMA-fragment order for the B-direct patch mainloop (conv.hip), or null:
+                        // [ceil(Cout/32)][Kpad/32][s 2][u 2][h 2][n 32][t 4] <- w[32 nt + n][32 ks + 16 s + 8 h + 4 u + t]
+  uint32_t w_frag_bytes;
   const void* w3;       // split-bf16 mode: the same matrix as three bf16 planes, [Cout][Kpad/32][3][32] (null: f32 path)
   int k_order;          // 0: k = (kh*KW + kw)*Cin + ci (tap-major)
                         // 1: k = ((ci/32)*KH*KW + kh*KW + kw)*32 + ci%32 (channel-block-major, Cin % 32 == 0):

@@ -30,6 +30,8 @@ SIGNATURES = {
     'dif_version': (c_int, []),
     'dif_last_error': (c_char_p, []),
     'dif_device_count': (c_int, []),
+    'dif_probe_mfma_clock': (c_int, [P(c_double), P(c_double), c_void_p]),
+    'dif_net_embed_clock': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, P(c_double), c_void_p]),
     'dif_pairwise': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     'dif_threshold_counts': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'dif_yolo_decode': (c_int, [P(c_void_p), P(ctypes.c_int32), P(c_float), c_int, c_int, c_int, c_int, c_int,

@@ -224,6 +224,20 @@ class DifEmbedder:
         N.check(N.lib.dif_net_embed_profile(self._h, N.ptr(t), n, layout, dtype, N.ptr(out), N.stream_ptr(), ms))
         return [(n, kn, m, float(ms[i])) for i, (n, kn, m) in enumerate(self.op_table())]
 
+    def held_clock_ghz(self, x):
+        """Shader clock (GHz) held inside the convolution kernels over one single-lane forward of the CUDA batch x
+        (diagnostic; include/dif.h: dif_net_embed_clock)."""
+        dev = N.require_device()
+        self._finalize()
+        t = x.to(dev).contiguous()
+        n = t.shape[0]
+        layout = N.LAYOUT_NHWC if tuple(t.shape[1:]) == self.input_shape else N.LAYOUT_NCHW
+        dtype = N.DTYPE_U8 if t.dtype == torch.uint8 else N.DTYPE_F32
+        out = torch.empty((n * sum(int(np.prod(s)) for s in self.output_shapes),), dtype=torch.float32, device=dev)
+        ghz = ctypes.c_double(0.0)
+        N.check(N.lib.dif_net_embed_clock(self._h, N.ptr(t), n, layout, dtype, N.ptr(out), ctypes.byref(ghz), N.stream_ptr()))
+        return ghz.value
+
     def predict_on_batch(self, x):
         """NumPy in -> NumPy float32 out (Keras semantics); torch in -> CUDA tensor out."""
         out = self.embed(x)

@@ -50,6 +50,10 @@ int dif_version(void);
 const char* dif_last_error(void);
 /* number of visible HIP devices (0 without a GPU); never fails */
 int dif_device_count(void);
+/* measurement aid (no reference counterpart): the shader clock in GHz that the current device holds under ~20 ms of
+ * back-to-back v_mfma_f32_32x32x2_f32 (pseudo-random operands) on every SIMD, and the TFLOP/s that loop sustained (may be null).  bench.py
+ * records it next to its rooflines, which price against the 2.4 GHz peak. */
+int dif_probe_mfma_clock(double* ghz_out, double* tflops_out, void* stream);
 
 /* ------------------------------------------------------------------ distances
  * Row-paired distance, out_dev[i] = d(e1[i], e2[i]); n1 or n2 may be 1 (NumPy
@@ -167,6 +171,11 @@ int dif_net_output_info(const dif_net* net, int i, int64_t shape[3]); /* {C,H,W}
 /* forward n <= max_batch images; x_dev is [n,H,W,3] (NHWC) or [n,3,H,W] (NCHW), f32 or u8;
  * out_dev is [n][emd] float32 (v3: [n,H,W,C] NHWC). */
 int dif_net_embed(dif_net* net, const void* x_dev, int n, int layout, int dtype, float* out_dev, void* stream);
+/* measurement aid: one forward of n images on a single lane whose convolution kernels record every block's life in
+ * shader cycles and in 100 MHz ticks; ghz_out = the life-weighted mean shader clock held inside those kernels
+ * (bench.py reports it beside rooflines priced at the 2.4 GHz peak) */
+int dif_net_embed_clock(dif_net* net, const void* x_dev, int n, int layout, int dtype, float* out_dev, double* ghz_out,
+                        void* stream);
 /* algorithmic FLOPs of one forward per image (2 * MACs of every conv/dense), for rooflines */
 double dif_net_flops_per_image(const dif_net* net);
 /* profiling aids: number of layer ops (= kernel launches) per forward, their names and

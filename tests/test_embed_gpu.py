@@ -372,3 +372,24 @@ def test_embed_bf16x3_mode_vs_oracle(cuda, arch, head, emd, n):
     assert not np.array_equal(got, ref)                            # ... and really another arithmetic
     f32.close()
     b3.close()
+
+
+def test_mfma_clock_probe(cuda):
+    """dif_probe_mfma_clock (measurement aid behind bench.py's `held_mfma_clock_ghz`): the clock held under back-to-back
+    f32 MFMAs lies between the 1.0 GHz floor seen under power caps and the 2.4 GHz peak, and the loop's own rate is
+    that clock's share of the 157.3 TFLOP/s peak (it issues nothing but MFMAs: within 10 %)."""
+    import ctypes
+    import torch
+    from deep_insight_face import _native as N
+    ghz, tf = ctypes.c_double(0.0), ctypes.c_double(0.0)
+    N.check(N.lib.dif_probe_mfma_clock(ctypes.byref(ghz), ctypes.byref(tf), torch.cuda.current_stream().cuda_stream))
+    assert 1.0 < ghz.value <= 2.45, ghz.value
+    assert 0.9 < tf.value / (157.3 * ghz.value / 2.4) < 1.05, (tf.value, ghz.value)
+    # ... and the clock inside the convolution kernels of a forward (every block records cycles and 100 MHz ticks)
+    model, _ = build('iresnet50', 'v2', 512, max_batch=64)
+    x = torch.from_numpy(crops_u8(64, seed=3)).cuda()
+    ref = model.embed(x)
+    conv_ghz = model.held_clock_ghz(x)
+    assert 1.0 < conv_ghz <= 2.45, conv_ghz
+    assert torch.equal(model.embed(x), ref)                    # the measuring forward leaves no state behind
+    model.close()
