@@ -331,6 +331,15 @@ constexpr int patch_lds_bytes(int emax) { return emax * 128 + 2 * 64 * 128; }
 constexpr int PATCH_PF_TAP = 4;                       // tap of the current slice at which the next patch is requested
 
 __device__ __forceinline__ int patch_swz(int entry) { return (entry >> 1) & 7; }
+// 8x8-tile form (AM = 6): image and first output pixel (h0, w0) of tile m0 / 64; returns that pixel's linear index
+__device__ __forceinline__ int tile2d_pix0(const ConvArgs& a, int m0, int& n, int& h0, int& w0) {
+  int r, hb, wb;
+  a.fd_t2_img.divmod(m0 >> 6, n, r);
+  a.fd_t2_w.divmod(r, hb, wb);
+  h0 = hb * 8;
+  w0 = wb * 8;
+  return (n * a.H + h0) * a.W + w0;
+}
 
 // T: the tile (BM output pixels, NT threads); EMAX: entries of the LDS patch
 template <class T, int EMAX_>
@@ -406,20 +415,12 @@ struct PatchA2D {
   int base[T::WM];
   int WP;
   // first output pixel (linear index) of tile m0 / 64
-  static __device__ __forceinline__ int pix0(const ConvArgs& a, int m0, int& n, int& h0, int& w0) {
-    int r, hb, wb;
-    a.fd_t2_img.divmod(m0 >> 6, n, r);
-    a.fd_t2_w.divmod(r, hb, wb);
-    h0 = hb * 8;
-    w0 = wb * 8;
-    return (n * a.H + h0) * a.W + w0;
-  }
   __device__ __forceinline__ PatchA2D(const ConvArgs& a, int m0) {
     static_assert(T::WM == 1 && T::BM == 64, "2-D patch: 64-pixel tile, one 32-row fragment per wave");
     const int tid = threadIdx.x, lane = tid & 63;
     WP = SIDE;
     int n, h0, w0;
-    pix0(a, m0, n, h0, w0);
+    tile2d_pix0(a, m0, n, h0, w0);
     const int64_t img_elems = (int64_t)a.H * a.W * a.Cin;
     rsrc = make_rsrc(a.x + n * img_elems, (uint32_t)(img_elems * 4));
     const int r = T::wave_row() * 32 + (lane & 31);
@@ -545,32 +546,39 @@ __device__ __forceinline__ void gemm_mainloop_patch_bd(const PA& pa, const ConvA
   const int h = lane >> 5;
   const int KS = a.Kpad / BK;
   const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.w_frag, a.w_frag_bytes);
-  // byte offset of this lane's piece (s, u) = q of K-step ks:  ((tile * KS + ks) * 4 + q) * 1024 + 16 lane
-  // (a column tile past ceil(Cout / 32) lies beyond the descriptor: reads zero)
+  // byte offset of this lane's piece (s, u) = q of K-step ks:  ((tile * KS + ks) * 4 + q) * 1024 + 16 lane.  The tile
+  // and lane part is the (bounds-checked) vector offset -- a column tile past ceil(Cout / 32) lies beyond the
+  // descriptor and reads zero --, the K-step part a scalar offset: no vector ALU work per step for B
   const uint32_t lane_off = (uint32_t)((n0 >> 5) + T::wave_col()) * (uint32_t)KS * 4096u + (uint32_t)lane * 16u;
   // half a K-step (s = 0 or 1: sixteen k, eight MFMAs) of fragments: pieces (s, 0) and (s, 1)
   auto bload = [&](int ks, int s, f32x4 (&b)[2]) {
-    const uint32_t vo = lane_off + (uint32_t)ks * 4096u + (uint32_t)s * 2048u;
-    b[0] = buf_load4(wrs, vo);
-    b[1] = buf_load4(wrs, vo + 1024u);
+    const uint32_t so = (uint32_t)ks * 4096u + (uint32_t)s * 2048u;
+    b[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane_off, so, 0));
+    b[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane_off + 1024u, so, 0));
   };
 
   f32x4 pr[PA::NPC], bA[2], bB[2];                         // bA: half s = 0 of the coming step, bB: half s = 1
   int cb = kbeg / 9, tap = kbeg - cb * 9;
+  // entry offset of the tap inside the patch, kh * WP + kw, kept as a scalar and stepped (no per-lane tap arithmetic)
+  int kw = tap % 3;
+  int eoff = (tap / 3) * pa.WP + kw;
   pa.load(cb, pr);
   bload(kbeg, 0, bA);
   pa.store(patch, pr);
   __syncthreads();
   bool pf_issued = false;
+  const char* patch_b = reinterpret_cast<const char*>(patch);
+  const uint32_t l0x = (uint32_t)(2 * h);                 // logical chunk of half 0, piece 0; the others are l0x | 1, | 4, | 5
+  // Byte address of chunk l0x of this lane's entry; chunk (l0x | d) sits at that address XOR 16 d: the swizzle is an XOR
+  // of the chunk index, and d touches other bits than l0x.
+  auto frag_addr = [&]() -> uint32_t {
+    const uint32_t e = (uint32_t)(pa.base[0] + eoff);
+    return (e << 7) | ((l0x ^ ((e >> 1) & 7u)) << 4);
+  };
   // one half-step: eight MFMAs on the A fragments of half s (read from the patch here) and the B fragments in b
-  auto half = [&](int s, const f32x4 (&b)[2]) {
-    const int kh = tap >= 6 ? 2 : (tap >= 3 ? 1 : 0);
-    const int e = pa.base[0] + kh * pa.WP + (tap - 3 * kh);
-    const int sa = patch_swz(e);
-    const float* pae = patch + e * 32;
-    const int l0 = 2 * h + 4 * s;                          // logical chunks l0, l0 + 1 (k = 16 s + 8 h .. + 7)
-    const f32x4 fa0 = *reinterpret_cast<const f32x4*>(pae + ((l0 ^ sa) << 2));
-    const f32x4 fa1 = *reinterpret_cast<const f32x4*>(pae + (((l0 + 1) ^ sa) << 2));
+  auto half = [&](uint32_t a0, int s, const f32x4 (&b)[2]) {
+    const f32x4 fa0 = *reinterpret_cast<const f32x4*>(patch_b + (a0 ^ (uint32_t)(64 * s)));
+    const f32x4 fa1 = *reinterpret_cast<const f32x4*>(patch_b + (a0 ^ (uint32_t)(64 * s + 16)));
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[t], b[0][t], acc[0][0], 0, 0, 0);
 #pragma unroll
@@ -583,13 +591,21 @@ __device__ __forceinline__ void gemm_mainloop_patch_bd(const PA& pa, const ConvA
       pa.load(cb + 1, pr);                                 // the next slice's patch: lands while taps PF_TAP .. 8 run
       pf_issued = true;
     }
+    const uint32_t a0 = frag_addr();
     __builtin_amdgcn_sched_barrier(0);
-    half(0, bA);
+    half(a0, 0, bA);
     bload(ks + 1, 0, bA);                                  // lands under the second half's MFMAs
     __builtin_amdgcn_sched_barrier(0);
-    half(1, bB);
+    half(a0, 1, bB);
+    if (++kw == 3) {
+      kw = 0;
+      eoff += pa.WP - 2;
+    } else {
+      ++eoff;
+    }
     if (++tap == 9) {
       tap = 0;
+      eoff = 0;
       ++cb;
       __syncthreads();                                     // every wave has read its last fragment of the old patch
       pa.store(patch, pr);
@@ -599,8 +615,9 @@ __device__ __forceinline__ void gemm_mainloop_patch_bd(const PA& pa, const ConvA
   }
   bload(ks, 1, bB);
   tail();
-  half(0, bA);
-  half(1, bB);
+  const uint32_t a0 = frag_addr();
+  half(a0, 0, bA);
+  half(a0, 1, bB);
   __syncthreads();
 }
 
@@ -693,7 +710,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
     int t2_pix0 = 0;
     if constexpr (TILE2D) {
       int n, h0, w0;
-      t2_pix0 = PatchA2D<T>::pix0(a, m0, n, h0, w0);
+      t2_pix0 = tile2d_pix0(a, m0, n, h0, w0);
     }
 #pragma unroll
     for (int i = 0; i < ITER; ++i) {
