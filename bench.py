@@ -316,6 +316,14 @@ def main():
 
     model = DifEmbedder(arch, head, 512, (112, 112, 3), max_batch=batch, compute=compute).init_synthetic(2024)
     model.set_input_transform(scale=1 / 255.)                 # predictions.py:154 `* rescale`, fused
+    # every embedding forward this process runs, by batch size (tools/check_profiles.py divides profiler totals by it)
+    forwards = {}
+    _embed = model.embed
+
+    def _counted_embed(x, *a, **k):
+        forwards[int(x.shape[0])] = forwards.get(int(x.shape[0]), 0) + 1
+        return _embed(x, *a, **k)
+    model.embed = _counted_embed
     lo, hi = shard_bounds(gallery_rows, world, rank)
     gal_full = synthetic_gallery(gallery_rows, 512, 7, 'cpu')
     shard = ShardedGallery(gal_full[lo:hi].to(dev), lo)
@@ -421,11 +429,13 @@ def main():
             for _ in range(max(3, min(args.steps, 10))):      # the governor settles over tens of ms: measure under the steps' load
                 model.embed(crops)
             conv_ghz = model.held_clock_ghz(crops)            # inside the conv kernels of one (single-lane) forward
+            forwards[batch] = forwards.get(batch, 0) + 1
         flops_embed = model.flops_per_image * batch            # algorithmic: 2 * MACs of every conv/dense
         if pipe is not None:
             flops_embed += det.flops_per_image * batch
         achieved = flops_embed / (embed_ms * 1e-3) / 1e12
         prof = model.profile(crops)
+        forwards[batch] = forwards.get(batch, 0) + 1
         det_ops = det.op_table() if pipe is not None else []
         conv_ms = sum(ms for _, k, _, ms in prof if k.startswith(('conv_igemm', 'stem')))
         conv_flops = sum(2 * macs * batch for _, k, macs, _ in prof if k.startswith(('conv_igemm', 'stem')))
@@ -447,6 +457,7 @@ def main():
                        'global_batch': world * batch, 'gallery_rows': gallery_rows,
                        'gallery_rows_per_gpu': hi - lo, 'emd': 512, 'metric': 'cosine',
                        'parallelism': 'dp%d + gallery row-shard' % world, 'backend': args.backend if world > 1 else None},
+            'forwards_in_process': {str(k): v for k, v in sorted(forwards.items())},
             'phases_ms': ({'embed': embed_ms, 'match': match_ms} if pipe is None else
                           {'detect+crop': float(np.mean([ev[i][0].elapsed_time(det_ms[i]) for i in range(args.steps)])),
                            'detect+crop+embed': embed_ms, 'match': match_ms}),

@@ -54,20 +54,27 @@ def main():
                      ('layers_r100_bf16x3.txt', 'r100_b256_bf16x3_layers.txt'), ('layers_yolov3.txt', 'yolov3_b64_layers.txt'),
                      ('latency.txt', 'latency.txt')):
         cp(src, R + '_' + src.replace(src, dst))
-    # forwards per profiled run: steps + warmup + 1 per-layer profile (+ 6 batch-256 forwards in the default workload)
+    # forwards per profiled run, in units of the workload's batch: bench.py reports them (`forwards_in_process`:
+    # steps + warmup, the per-layer profile, the warm-up and the stamped forward of the clock measurement, and the
+    # batch-256 forwards of the default workload)
+    def equiv_forwards(tag, batch):
+        f = jl(os.path.join(OUT, tag + '.json'))['forwards_in_process']
+        return sum(int(b) * n for b, n in f.items()) / float(batch)
     tool('pmc_traffic.py', [os.path.join(OUT, 'pf_default/p_counter_collection.csv'),
-                            os.path.join(OUT, 'pw_default/p_counter_collection.csv'), '8'], R + '_r100_1m_b512_hbm_traffic.json')   # 5 forwards of 512 + 6 of 256
+                            os.path.join(OUT, 'pw_default/p_counter_collection.csv'), '%g' % equiv_forwards('pf_default', 512)],
+         R + '_r100_1m_b512_hbm_traffic.json')
     tool('pmc_traffic.py', [os.path.join(OUT, 'pf_r100/p_counter_collection.csv'),
-                            os.path.join(OUT, 'pw_r100/p_counter_collection.csv'), '5'], R + '_r100_b256_hbm_traffic.json')
+                            os.path.join(OUT, 'pw_r100/p_counter_collection.csv'), '%g' % equiv_forwards('pf_r100', 256)],
+         R + '_r100_b256_hbm_traffic.json')
     tool('pmc_traffic.py', [os.path.join(OUT, 'pf_r50/p_counter_collection.csv'),
-                            os.path.join(OUT, 'pw_r50/p_counter_collection.csv'), '5'], R + '_r50_b256_hbm_traffic.json')
+                            os.path.join(OUT, 'pw_r50/p_counter_collection.csv'), '%g' % equiv_forwards('pf_r50', 256)],
+         R + '_r50_b256_hbm_traffic.json')
     tool('pmc_mfma.py', [os.path.join(OUT, 'pm_default/p_counter_collection.csv')], R + '_r100_1m_mfma_util.json')
 
-    # cross-check 1: default workload, ONE lane.  forwards of batch 512 in the profiled run: 20 + 5 + 1 profile
-    # = 26, plus 1 + max(5, min(20, 20)) = 21 forwards of batch 256 (= 10.5 forwards of 512 in conv time)
+    # cross-check 1: default workload, ONE lane: every forward of the profiled process, in batch-512 equivalents
     one = jl(os.path.join(OUT, 'ks_default_1lane.json'))
     ms, calls = conv_ms(os.path.join(OUT, 'ks_default_1lane/p_kernel_stats.csv'))
-    fw = 26 + 21 * 0.5
+    fw = equiv_forwards('ks_default_1lane', 512)
     per_fw = ms / fw
     flops = one['roofline']['algorithmic_flops_per_forward']
     lines.append('default workload (IResNet-100, 512 faces, 1M gallery), ONE lane, under rocprofv3: %d conv launches, '
@@ -82,11 +89,12 @@ def main():
                  % (d['value'], d['roofline']['forward_ms_hip_events'], d['roofline']['frac'],
                     d['roofline']['b256']['forward_ms_hip_events'], d['roofline']['b256']['frac'], d['phases_ms']['match'],
                     dp['value'], dp['roofline']['frac']))
-    # cross-check 2: ResNet-50V2 one lane: 10 + 3 + 1 forwards
+    # cross-check 2: ResNet-50V2 one lane
     r50 = jl(os.path.join(OUT, 'bench_r50_1lane.json'))
     ms, calls = conv_ms(os.path.join(OUT, 'ks_r50_1lane/p_kernel_stats.csv'))
+    fw50 = equiv_forwards('ks_r50_1lane', 256)
     lines.append('r50 (configs[1]), ONE lane: %d conv launches per forward, %.3f ms of conv kernels per forward (stats) vs HIP-event '
-                 'forward %.3f ms (un-profiled run), frac %.4f' % (calls // 14, ms / 14, r50['roofline']['forward_ms_hip_events'],
+                 'forward %.3f ms (un-profiled run), frac %.4f' % (round(calls / fw50), ms / fw50, r50['roofline']['forward_ms_hip_events'],
                                                                   r50['roofline']['frac']))
     for w in ('r100', 'r50', 'r100_arc', 'r100_1m_bf16x3', 'frames'):
         b = jl(os.path.join(OUT, 'bench_%s.json' % w))

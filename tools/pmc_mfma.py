@@ -7,12 +7,12 @@ GRBM_GUI_ACTIVE is summed over the 8 XCDs, so kernel cycles = GRBM_GUI_ACTIVE / 
 
     MFMA busy fraction (of GRBM cycles) = SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles * 1024 SIMDs).
 
-Caveat (MI355X_MICROARCH.md "DVFS give-back"): GRBM_GUI_ACTIVE / 8 / duration reads HIGH on dispatches
-shorter than a few ms -- it gives 2.4-2.5 GHz here while s_memtime / s_memrealtime inside the same
-kernels shows the shader clock held at 2.03 GHz (profiles/r01_conv_trace.txt).  The clock-free number
-is `mfma_busy_cycles_per_simd_per_ns` (= busy GHz): divided by 2.4 it is the fraction of the 157.3 TFLOP/s
-peak the issued MFMAs amount to (padding and tile tails included); divided by the held clock (2.03)
-it is how busy the matrix pipe really is.
+Clock: GRBM_GUI_ACTIVE / 8 / duration is the shader clock over the dispatch (it reads high on dispatches much
+shorter than 0.3 ms: MI355X_MICROARCH.md "DVFS give-back"); on the 0.5 ms convolution launches it agrees with the
+in-kernel s_memtime / s_memrealtime ratio that bench.py records (dif_net_embed_clock: 2.34-2.38 GHz on round 2's
+boxes; round 1's box held 2.03 GHz).  `mfma_busy_cycles_per_simd_per_ns` is clock-free: divided by 2.4 it is the
+fraction of the 157.3 TFLOP/s peak the issued MFMAs amount to (padding and tile tails included);
+`mfma_busy_frac_of_grbm_cycles` is how busy the matrix pipe is at the clock the dispatch ran at.
 
     python tools/pmc_mfma.py <counter_collection.csv>
 """
@@ -50,8 +50,7 @@ def main():
         out[k] = {'launches': int(a['launches']), 'total_ms': a['ns'] / 1e6,
                   'mfma_busy_cycles_per_simd_per_ns': busy_ghz,
                   'issued_mfma_frac_of_157.3TF_peak': busy_ghz / 2.4,
-                  'mfma_pipe_busy_at_held_clock_2.03GHz': busy_ghz / 2.03,
-                  'grbm_clock_ghz_unreliable_on_short_dispatches': ghz, 'mfma_busy_frac_of_grbm_cycles': busy}
+                  'grbm_clock_ghz': ghz, 'mfma_busy_frac_of_grbm_cycles': busy}
     print(json.dumps(out, indent=1))
 
 
