@@ -537,9 +537,10 @@ __device__ __forceinline__ void gemm_mainloop_patch(const PA& pa, BLoader& bl, i
 // are (a whole step ahead costs 16 more registers: 120 spilled).  LDS then
 // holds the A patch only, and the block synchronises only when the patch is replaced: two barriers per NINE K-steps
 // instead of ten.  (Both waves of a column pair fetch the same KB: the second hits L1/L2; 16 KB per block per step.)
-template <class T, class PA, class Tail>
+// `pre()` runs before the MFMAs of every K-step, `post()` after them: conv_bdp_kernel retires the previous tile there.
+template <class T, class PA, class Tail, class Pre, class Post>
 __device__ __forceinline__ void gemm_mainloop_patch_bd(const PA& pa, const ConvArgs& a, int n0, int kbeg, int kend,
-                                                       float* lds, f32x16 (&acc)[1][1], Tail&& tail) {
+                                                       float* lds, f32x16 (&acc)[1][1], Tail&& tail, Pre&& pre, Post&& post) {
   static_assert(T::BM == 64 && T::BN == 64 && T::NT == 256, "patch path: 64x64 tile");
   float* patch = lds;
   const int lane = threadIdx.x & 63;
@@ -591,12 +592,14 @@ __device__ __forceinline__ void gemm_mainloop_patch_bd(const PA& pa, const ConvA
       pa.load(cb + 1, pr);                                 // the next slice's patch: lands while taps PF_TAP .. 8 run
       pf_issued = true;
     }
+    pre();
     const uint32_t a0 = frag_addr();
     __builtin_amdgcn_sched_barrier(0);
     half(a0, 0, bA);
     bload(ks + 1, 0, bA);                                  // lands under the second half's MFMAs
     __builtin_amdgcn_sched_barrier(0);
     half(a0, 1, bB);
+    post();
     if (++kw == 3) {
       kw = 0;
       eoff += pa.WP - 2;
@@ -615,9 +618,11 @@ __device__ __forceinline__ void gemm_mainloop_patch_bd(const PA& pa, const ConvA
   }
   bload(ks, 1, bB);
   tail();
+  pre();
   const uint32_t a0 = frag_addr();
   half(a0, 0, bA);
   half(a0, 1, bB);
+  post();
   __syncthreads();
 }
 
@@ -869,7 +874,7 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const 
       else if constexpr (BD)
         gemm_mainloop_patch_bd<T>(al, a, n0, k0, k1, smem, acc, [&] {
           if (prefetch_res && a.res) er.load(a, m0, n0);
-        });
+        }, [] {}, [] {});
       else if constexpr (PATCH)
         gemm_mainloop_patch<T>(al, bl, k0, k1, smem, acc, [&] {
           if (prefetch_res && a.res) er.load(a, m0, n0);
@@ -1226,6 +1231,220 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_pipe_kernel(const C
   epi_pre(std::integral_constant<int, 7>()); epi_post(std::integral_constant<int, 7>());
 }
 
+// ------------------------------------------------------------------------------------------
+// B-direct patch kernel with the epilogue taken out of the block's critical path (AMP = patch form 3 / 5 / 6).
+//
+// In conv_igemm_kernel a block stops issuing MFMAs for ~10 us per tile: the staged epilogue (shortcut rows fetched one
+// after the other) and the next tile's set-up.  That is 7 % of a 72-step tile, 14 % of a 36-step one (28x28 stage) and
+// 24 % of an 18-step one (64-channel layers).  Here, as in conv_pipe_kernel, a finished tile's accumulators move to a
+// second register set and are retired two registers per K-step during the NEXT part's first eight K-steps: shortcut
+// values requested before a step's MFMAs, scale / shift / activation / add / stores after them, straight from the MFMA
+// layout (32 channels x two rows per instruction = two 128-byte segments), no LDS, no barrier.  The grid is always the
+// persistent stream-K one (also for short K loops: the partial-tile hand-off costs less than a non-persistent block's
+// set-up per tile).  Same arithmetic per output element as conv_epilogue, in the same order.
+// Launcher restrictions: plain output geometry, unit-stride shortcut, no RELU6, 32-bit byte offsets (conv_bdp_ok).
+template <class T, int AMP>
+__global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_bdp_kernel(const ConvArgs a) {
+  static_assert(T::WM == 1 && T::WN == 1 && T::BM == 64 && T::BN == 64, "64x64 tile, one 32x32 fragment per wave");
+  using PA = typename std::conditional<AMP == 3, PatchA<T, PATCH_EMAX_S>,
+                                       typename std::conditional<AMP == 5, PatchA<T, PATCH_EMAX_L>, PatchA2D<T>>::type>::type;
+  constexpr bool TILE2D = AMP == 6;
+  constexpr int SLAB = T::BM * T::BN;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  // behind the patch: the retiring tile's accumulators, register r of thread t at [r][t] (lane-private: no barrier, no
+  // bank conflict), then the stream-K time-out word
+  float* accp = smem + PA::EMAX * 32 + threadIdx.x;
+  int* s_timeout = reinterpret_cast<int*>(smem + PA::EMAX * 32 + 16 * T::NT);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int P = gridDim.x;
+  const int p = xcd_remap(blockIdx.x, P);
+  const int KS = a.Kpad / BK;
+  const int tiles_n = (a.Cout + T::BN - 1) / T::BN;
+  const int tiles_m = (a.M + T::BM - 1) / T::BM;
+  const int I = tiles_m * tiles_n * KS;
+  auto sk_begin = [&](int q) -> int { return (int)((int64_t)I * q / P); };
+  const int beg = sk_begin(p), end = sk_begin(p + 1);
+  const unsigned long long tr_t0 = a.trace ? __builtin_amdgcn_s_memrealtime() : 0;
+  const unsigned long long tr_c0 = a.trace ? __builtin_amdgcn_s_memtime() : 0;
+
+  // ---- the tile being retired (registers 2J, 2J + 1 of accp are chunk J; p_next = next chunk, 8 = nothing pending)
+  int p_next = 8, p_row0 = 0, pcol = 0, row_lim = 0;
+  float sc = 1.f, sh = 0.f, sl = 1.f, sc2 = 1.f, sh2 = 0.f, sl2 = 1.f;
+  float rres[2], av[2];
+  const int erow_l = T::wave_row() * 32 + 4 * (lane >> 5);
+  const int ecol_l = T::wave_col() * 32 + (lane & 31);
+  // branch-free accesses: an out-of-range offset reads zero / is dropped, a null tensor gets an empty descriptor
+  const __amdgpu_buffer_rsrc_t res_rsrc = make_rsrc(a.res, a.res ? (uint32_t)((int64_t)a.M * a.Cout * 4) : 0u);
+  const __amdgpu_buffer_rsrc_t y_rsrc = make_rsrc(a.y, a.y ? (uint32_t)((int64_t)a.M * a.Cout * 4) : 0u);
+  const __amdgpu_buffer_rsrc_t y2_rsrc = make_rsrc(a.y2, a.y2 ? (uint32_t)((int64_t)a.M * a.Cout * 4) : 0u);
+  auto chunk_row = [&](int r) -> int {                     // output pixel (linear index) of accumulator register r
+    const int rl = erow_l + (r & 3) + 8 * (r >> 2);
+    return TILE2D ? p_row0 + (rl >> 3) * a.W + (rl & 7) : p_row0 + rl;
+  };
+  // Chunk j = accumulator registers 2j, 2j + 1, kept in LDS (in registers the set costs 16 VGPRs the K loop does not have:
+  // 44-64 spilled; a switch over static register indices made the compiler clone the K loop): pre() requests the two
+  // values and the two shortcut values before the step's MFMAs, post() uses them after.
+  auto retire_pre = [&](int j) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int row = chunk_row(2 * j + q);
+      const uint32_t off = (uint32_t)(row * a.Cout + pcol) * 4u;
+      rres[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(res_rsrc, row < row_lim ? off : OOB, 0, 0));
+      av[q] = accp[(2 * j + q) * T::NT];
+    }
+  };
+  auto retire_post = [&](int j) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int row = chunk_row(2 * j + q);
+      const float v = fmaf(av[q], sc, sh);
+      const float t = (v >= 0.f ? v : v * sl) + rres[q];
+      const float u = fmaf(t, sc2, sh2);
+      const uint32_t o = row < row_lim ? (uint32_t)(row * a.Cout + pcol) * 4u : OOB;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, t), y_rsrc, o, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, u >= 0.f ? u : u * sl2), y2_rsrc, o, 0, 0);
+    }
+  };
+  auto hook_pre = [&]() {
+    if (p_next < 8) retire_pre(p_next);
+  };
+  auto hook_post = [&]() {
+    if (p_next < 8) {
+      retire_post(p_next);
+      ++p_next;
+    }
+  };
+  auto flush = [&]() {                                     // whatever the K-steps could not carry
+    while (p_next < 8) {
+      retire_pre(p_next);
+      retire_post(p_next);
+      ++p_next;
+    }
+  };
+
+  int it = beg;
+  while (it < end) {
+    int tile, kb, mt, nt;
+    a.fd_ks.divmod(it, tile, kb);
+    const int left = end - it;
+    const int ke = (KS - kb <= left) ? KS : kb + left;
+    a.fd_tiles_n.divmod(tile, mt, nt);
+    const int m0 = mt * T::BM, n0 = nt * T::BN;
+    f32x16 acc[1][1];
+    zero_acc<T>(acc);
+    PA al(a, m0);
+    gemm_mainloop_patch_bd<T>(al, a, n0, kb, ke, smem, acc, [] {}, hook_pre, hook_post);
+
+    if (kb != 0) {
+      // not the owner of this tile: publish the partial accumulators (fragment order, 16 B per lane)
+      float* slab = a.sk_slab + (int64_t)p * SLAB;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v = {acc[0][0][4 * q], acc[0][0][4 * q + 1], acc[0][0][4 * q + 2], acc[0][0][4 * q + 3]};
+        *reinterpret_cast<f32x4*>(slab + (q * T::NT + tid) * 4) = v;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(a.sk_flag + p, a.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+      // owner: collect the rest of the K range from the blocks that follow
+      int kdone = ke;
+      int q = p;
+      while (kdone < KS) {
+        ++q;
+        const int qb = sk_begin(q), qe = sk_begin(q + 1);
+        const int q_kb = qb - tile * KS;
+        const int q_len = qe - qb;
+        const int q_ke = (KS - q_kb <= q_len) ? KS : q_kb + q_len;
+        if (tid == 0) {
+          int spins = 0, timeout = a.sk_spin_limit < 0 ? 1 : 0;
+          while (!timeout && __hip_atomic_load(a.sk_flag + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.sk_epoch) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > a.sk_spin_limit) {
+              timeout = 1;
+              break;
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          *s_timeout = timeout;
+        }
+        __syncthreads();
+        const int timeout = *s_timeout;
+        __syncthreads();
+        if (!timeout) {
+          const float* slab = a.sk_slab + (int64_t)q * SLAB;
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(slab + (r4 * T::NT + tid) * 4);
+            acc[0][0][4 * r4] += v[0];
+            acc[0][0][4 * r4 + 1] += v[1];
+            acc[0][0][4 * r4 + 2] += v[2];
+            acc[0][0][4 * r4 + 3] += v[3];
+          }
+        } else {
+          // the partner is not co-resident: compute its K range here, from zero like its slab, and add (same bits)
+          float* stash = a.sk_slab + ((int64_t)P + p) * SLAB;
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            f32x4 v = {acc[0][0][4 * r4], acc[0][0][4 * r4 + 1], acc[0][0][4 * r4 + 2], acc[0][0][4 * r4 + 3]};
+            *reinterpret_cast<f32x4*>(stash + (r4 * T::NT + tid) * 4) = v;
+          }
+          zero_acc<T>(acc);
+          gemm_mainloop_patch_bd<T>(al, a, n0, q_kb, q_ke, smem, acc, [] {}, hook_pre, hook_post);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(stash + (r4 * T::NT + tid) * 4);
+            acc[0][0][4 * r4] = v[0] + acc[0][0][4 * r4];
+            acc[0][0][4 * r4 + 1] = v[1] + acc[0][0][4 * r4 + 1];
+            acc[0][0][4 * r4 + 2] = v[2] + acc[0][0][4 * r4 + 2];
+            acc[0][0][4 * r4 + 3] = v[3] + acc[0][0][4 * r4 + 3];
+          }
+        }
+        kdone = q_ke;
+      }
+      // hand the finished tile over to the retiring set
+      flush();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accp[r * T::NT] = acc[0][0][r];
+      pcol = n0 + ecol_l;
+      if constexpr (TILE2D) {
+        int n, h0, w0;
+        p_row0 = tile2d_pix0(a, m0, n, h0, w0);
+      } else {
+        p_row0 = m0;
+      }
+      if (pcol < a.Cout) {
+        row_lim = a.M;
+        sc = a.scale ? a.scale[pcol] : 1.f;
+        sh = a.shift ? a.shift[pcol] : 0.f;
+        sc2 = a.scale2 ? a.scale2[pcol] : 1.f;
+        sh2 = a.shift2 ? a.shift2[pcol] : 0.f;
+        sl = a.act == ACT_RELU ? 0.f : (a.act == ACT_PRELU ? (a.alpha ? a.alpha[pcol] : 0.f) : 1.f);
+        sl2 = a.act2 == ACT_RELU ? 0.f : (a.act2 == ACT_PRELU ? (a.alpha2 ? a.alpha2[pcol] : 0.f) : 1.f);
+      } else {
+        row_lim = 0;
+      }
+      p_next = 0;
+    }
+    it += ke - kb;
+  }
+  flush();                                                 // the last tile has no successor to hide behind
+  if (a.trace && tid == 0) {
+    unsigned long long* t = a.trace + (size_t)blockIdx.x * 8;
+    t[0] = t[1] = t[2] = t[3] = t[4] = 0;
+    t[5] = tr_t0;
+    t[6] = __builtin_amdgcn_s_memrealtime();
+    t[7] = 1 | ((__builtin_amdgcn_s_memtime() - tr_c0) << 8);
+  }
+}
+
 // Per-device launch state.  One process drives one GPU by convention, but nothing here depends on it:
 // the CU count and the "dynamic LDS limit raised" bit of every kernel are cached per device ordinal.
 constexpr int kMaxDevices = 64;
@@ -1293,6 +1512,58 @@ static int launch_conv_pipe(const ConvArgs& a, hipStream_t st) {
   return 0;
 }
 
+// conv_bdp_kernel's restrictions (otherwise the launcher keeps conv_igemm_kernel's B-direct form)
+static bool conv_bdp_ok(const ConvArgs& a) {
+  static const bool on = !(getenv("DIF_NO_BDP") && atoi(getenv("DIF_NO_BDP")));
+  // 64-channel layers (18 K-steps per tile) measured 2 % faster one tile per block than on the persistent grid
+  static const int min_ks = getenv("DIF_BDP_MIN_KS") ? atoi(getenv("DIF_BDP_MIN_KS")) : 32;
+  if (!on || a.bdp_mode == 1 || !a.w_frag || a.y_sub) return false;
+  if (a.bdp_mode != 2 && a.Kpad / BK < min_ks) return false;
+  if (!(a.y_H == a.Ho && a.y_W == a.Wo && a.y_oy == 0 && a.y_ox == 0 && a.y_ld == a.Cout && a.y_coff == 0)) return false;
+  if (a.res && (a.res_stride != 1 || a.res_H != a.Ho || a.res_W != a.Wo)) return false;
+  if (a.act == ACT_RELU6 || a.act2 == ACT_RELU6) return false;
+  if ((int64_t)a.M * a.Cout * 4 >= 0xFFFFFFF0LL) return false;
+  // more than one tile per resident block (DIF_BDP_MIN_TILES, default 1.5), or there is no next tile to retire the previous one under (ResNet50V2's 3x3
+  // layers on half-chip lane grids: 0.8-1.5 tiles per block, 1 % slower here than on conv_igemm_kernel)
+  const int64_t tiles = ((a.M + 63) / 64) * (int64_t)((a.Cout + 63) / 64);
+  int64_t slots = 4 * (int64_t)num_cus();
+  if (slots > a.sk_max_blocks) slots = a.sk_max_blocks;
+  static const double min_tiles = getenv("DIF_BDP_MIN_TILES") ? atof(getenv("DIF_BDP_MIN_TILES")) : 1.5;
+  return a.bdp_mode == 2 || (double)tiles >= min_tiles * (double)slots;
+}
+
+template <class T, int AMP>
+static int launch_conv_bdp(const ConvArgs& a, hipStream_t st) {
+  auto kern = conv_bdp_kernel<T, AMP>;
+  constexpr int emax = AMP == 3 ? PATCH_EMAX_S : (AMP == 5 ? PATCH_EMAX_L : 100);
+  constexpr int lds_bytes = emax * 128 + 16 * T::NT * 4 + 16;      // patch + retiring accumulators + time-out word
+  if (allow_dynamic_lds(kern, lds_bytes)) return -1;
+  const int64_t tiles = ((a.M + T::BM - 1) / T::BM) * (int64_t)((a.Cout + T::BN - 1) / T::BN);
+  const int KS = a.Kpad / BK;
+  const int64_t I = tiles * KS;
+  if (I >= 0x7fffffffLL) return set_error("conv: iteration space too large");
+  int64_t P = T::BLOCKS_PER_CU * (int64_t)num_cus();
+  if (P > a.sk_max_blocks) P = a.sk_max_blocks;
+  if (P > (I + 3) / 4) P = (I + 3) / 4;
+  if (P < 1) P = 1;
+  ConvArgs b = a;
+  b.sk_skew_q16 = 0;
+  b.fd_howo = make_fastdiv(a.Ho * a.Wo);
+  b.fd_wo = make_fastdiv(a.Wo);
+  b.fd_cin = make_fastdiv(a.Cin);
+  b.fd_kw = make_fastdiv(a.KW);
+  b.fd_ks = make_fastdiv(KS);
+  b.fd_taps = make_fastdiv(a.KH * a.KW);
+  b.fd_wp = make_fastdiv(a.W + 2);
+  b.fd_rpi = make_fastdiv(a.H + 1);
+  b.fd_t2_w = make_fastdiv(a.W / 8 > 0 ? a.W / 8 : 1);
+  b.fd_t2_img = make_fastdiv((a.H / 8) * (a.W / 8) > 0 ? (a.H / 8) * (a.W / 8) : 1);
+  b.fd_tiles_n = make_fastdiv((a.Cout + T::BN - 1) / T::BN);
+  hipLaunchKernelGGL(kern, dim3((unsigned)P), dim3(T::NT), lds_bytes, st, b);
+  DIF_HIP(hipGetLastError());
+  return 0;
+}
+
 // 3x3 / stride 1 / pad 1, whole 32-channel slices in channel-block-major K order, plain output geometry, and a
 // 64-pixel tile's halo patch bounded by PATCH_EMAX entries (row wraps add 2 entries each, an image boundary adds
 // one padded row).  IResNet's 28x28, 14x14 and 7x7 stages qualify; 56x56 and up keep the per-K-step gather.
@@ -1354,8 +1625,10 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
     static const bool p2d_first = !(getenv("DIF_PATCH2D_FIRST") && !atoi(getenv("DIF_PATCH2D_FIRST")));
     static const bool use_bd = !(getenv("DIF_NO_BD") && atoi(getenv("DIF_NO_BD")));
     const bool bd = use_bd && a.w_frag != nullptr;
-    if (!use_dma && p2d_first && patch2d_applies(a))
+    if (!use_dma && p2d_first && patch2d_applies(a)) {
+      if (bd && conv_bdp_ok(a)) return launch_conv_bdp<T, 6>(a, st);
       return bd ? launch_conv_pre<T, false, false, 16>(a, st) : launch_conv_pre<T, false, false, 6>(a, st);
+    }
     if (!use_dma && a.Cin % 4 == 0 && pipe_applies(a, tiles, a.Kpad / BK, slots)) {
       // pointwise layers retire the previous tile four chunks per K-step, i.e. within the first two
       // steps (measured best for every K: 2 steps +16 %, 8 steps +5 % over one chunk per step); the
@@ -1372,6 +1645,11 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
       static const bool use_bd2 = !(getenv("DIF_NO_BD") && atoi(getenv("DIF_NO_BD")));
       const bool bd2 = use_bd2 && a.w_frag != nullptr;
       const int emax = patch_applies(a);
+      if (bd2 && conv_bdp_ok(a)) {
+        if (emax == PATCH_EMAX_S) return launch_conv_bdp<T, 3>(a, st);
+        if (emax == PATCH_EMAX_L) return launch_conv_bdp<T, 5>(a, st);
+        if (patch2d_applies(a)) return launch_conv_bdp<T, 6>(a, st);
+      }
       if (emax == PATCH_EMAX_S) return bd2 ? launch_conv_pre<T, false, false, 13>(a, st) : launch_conv_pre<T, false, false, 3>(a, st);
       if (emax == PATCH_EMAX_L) return bd2 ? launch_conv_pre<T, false, false, 15>(a, st) : launch_conv_pre<T, false, false, 5>(a, st);
       if (patch2d_applies(a)) return bd2 ? launch_conv_pre<T, false, false, 16>(a, st) : launch_conv_pre<T, false, false, 6>(a, st);

@@ -1075,7 +1075,7 @@ int Net::finalize(int mb) {
   const double per_launch = flops_per_image() * (max_batch / 2) / (n_conv > 0 ? n_conv : 1);
   const bool long_launches = per_launch >= 10e9;
   int nl = getenv("DIF_STREAMS") ? atoi(getenv("DIF_STREAMS")) : 2;
-  const int lane_split = getenv("DIF_SK_LANE_SPLIT") ? atoi(getenv("DIF_SK_LANE_SPLIT")) : (long_launches ? 0 : 1);
+  lane_split = (getenv("DIF_SK_LANE_SPLIT") ? atoi(getenv("DIF_SK_LANE_SPLIT")) : (long_launches ? 0 : 1)) != 0;
   if (nl < 1) nl = 1;
   if (nl > 8) nl = 8;
   if (max_batch < 64 * nl || !extra_outputs.empty()) nl = 1;
@@ -1229,6 +1229,7 @@ int Net::run_op(const Op& op, Lane& L, const void* xin, int n, int layout, int d
       a.sk_epoch = ++L.sk_epoch;
       a.sk_spin_limit = sk_spin_limit;
       a.use_pipe = use_pipe;
+      a.bdp_mode = use_bdp == 2 ? 2 : ((use_bdp == 0 || lane_split) ? 1 : 0);
       a.trace = trace_buf ? trace_buf + trace_off[&op - ops.data()] * 8 : nullptr;
       if (op.d_w_raw && op.stem_mfma && use_stem) {
         if (stem_mfma_run(a.x, op.d_w_raw, a.scale, a.shift, a.alpha, a.scale2, a.shift2, a.alpha2, a.y, a.y2, n, a.H, a.W,

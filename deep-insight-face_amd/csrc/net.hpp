@@ -125,12 +125,14 @@ struct Net {
   };
   std::vector<Lane> lanes;
   hipEvent_t ev_start = nullptr;
+  bool lane_split = false;          // the lanes' persistent grids take 1 / nl of the resident slots each (short launches)
   bool lanes_active = false;        // this forward runs on all lanes (each with its share of the resident slots)
   std::vector<int64_t> buf_elems;   // per image
   int sk_max_blocks = 0;
   int sk_spin_limit = 1 << 18;
   int compute_bf16x3 = 0;           // option "bf16x3" (set before finalize): convolutions on the split-bf16 MFMA path
   int use_pipe = 1;                 // option "pipe": 0 keeps every convolution on conv_igemm_kernel
+  int use_bdp = 1;                  // option "bdp": 0 never conv_bdp_kernel, 1 where it pays, 2 wherever it can run
   int use_stem = 1;                 // option "stem": 0 runs 3-channel first layers on conv_igemm_kernel too
 
   ~Net();

@@ -103,6 +103,11 @@ int dif_net_set_option(dif_net* h, const char* key, int value) {
     h->net.use_pipe = value != 0;
     return 0;
   }
+  if (!strcmp(key, "bdp")) {
+    if (value < 0 || value > 2) return set_error("dif_net_set_option: 'bdp' takes 0, 1 or 2");
+    h->net.use_bdp = value;
+    return 0;
+  }
   if (!strcmp(key, "stem")) {
     h->net.use_stem = value != 0;
     return 0;

@@ -84,6 +84,9 @@ struct ConvArgs {
   int sk_max_blocks;
   int sk_skew_q16;      // stream-K share skew by resident slot, Q16 (conv.hip: sk_begin); filled by conv_run
   int sk_spin_limit;    // polls before the owner computes a missing K range itself; < 0: always (test hook)
+  int bdp_mode;         // conv_bdp_kernel for the patch layers: 0 where it pays (conv.hip: conv_bdp_ok), 1 never (set where
+                        // launches are short and the lanes run half-chip grids: measured 1-2 % slower there; Net option
+                        // "bdp" = 0), 2 wherever its restrictions allow (Net option "bdp" = 2: the parity tests)
   int use_pipe;         // 0: never take the software-pipelined kernel (Net option "pipe"; tests compare both paths)
   int dbg;              // development aid: bit 0 drops the pipelined kernel's stores, bit 1 its shortcut loads
   // development aid (tools/ubench/conv_trace.hip), null in the library: 4 x u64 per hardware block =

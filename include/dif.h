@@ -157,6 +157,9 @@ int dif_net_finalize(dif_net* net, int max_batch);
 /* execution options (no reference counterpart: Keras picks its kernels by itself).  Keys:
  *   "pipe"  1 (default) lets short-K convolutions take the software-pipelined kernel, 0 keeps every
  *           convolution on the plain implicit-GEMM kernel (the two are compared by the parity tests)
+ *   "bdp"   1 (default) lets 3x3 / stride 1 layers with several tiles per resident block take the kernel that retires a
+ *           tile's epilogue inside the next tile's K-steps (conv.hip: conv_bdp_kernel), 0 never, 2 wherever its
+ *           restrictions allow (the parity tests compare 0 and 2)
  *   "stem"  1 (default) runs 3-channel first layers on their own kernels (stem.hip, elementwise.hip), 0 on the general
  *           implicit-GEMM kernel (compared by the parity tests)
  *   "bf16x3" 0 (default): float32 MFMA, a bit-exact f32 fma chain -- the reference's arithmetic;

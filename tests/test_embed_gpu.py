@@ -266,6 +266,35 @@ def test_pipelined_kernel_equals_plain_kernel(cuda, monkeypatch):
         m.close()
 
 
+def test_deferred_epilogue_kernel_equals_plain_kernel(cuda, monkeypatch):
+    """3x3 / stride 1 layers with several tiles per resident block run on conv_bdp_kernel: B fragments straight from L2,
+    a finished tile's accumulators parked in LDS and retired two registers per K-step inside the next tile's K loop,
+    always on the persistent stream-K grid.  Option 'bdp' = 2 forces it wherever its restrictions allow (also onto tiny
+    grids, tiles split between blocks, 8x8-tile and linear patches, ragged last tiles), 'bdp' = 0 keeps
+    conv_igemm_kernel: same products, same order per output element, so the embeddings agree to float32 rounding of the
+    ReLU's zero sign.  Run once more with the stream-K owner forced to recompute its partners' ranges
+    (DIF_SK_SPIN_LIMIT=-1: the rare branch of the hand-over)."""
+    import torch
+    from deep_insight_face.networks.triplet import DifEmbedder
+    rng = np.random.default_rng(44)
+    for arch, n, spin in (('iresnet50', 37, None), ('resnet', 70, None), ('vgg16', 5, None), ('iresnet50', 9, '-1')):
+        if spin is not None:
+            monkeypatch.setenv('DIF_SK_SPIN_LIMIT', spin)
+        x = torch.from_numpy(rng.integers(0, 256, (n, 112, 112, 3), dtype=np.uint8)).cuda()
+        m = DifEmbedder(arch, 'v2', 512, (112, 112, 3), max_batch=n).init_synthetic(11)
+        m.set_input_transform(scale=1 / 255.)
+        m.set_option('bdp', 2)
+        a = m.embed(x)
+        a2 = m.embed(x)
+        m.set_option('bdp', 0)
+        b = m.embed(x)
+        assert torch.equal(a, a2)                                         # deterministic
+        assert float((a - b).abs().max()) <= 2e-6, arch
+        m.close()
+        if spin is not None:
+            monkeypatch.delenv('DIF_SK_SPIN_LIMIT')
+
+
 def test_stem_kernels_equal_general_kernel(cuda):
     """3-channel first layers run on their own kernels: IResNet's 3x3 and ResNet50V2's 7x7 / stride 2 (64 filters) on
     the MFMA with the input patch in LDS and the true K (stem.hip), YOLOv3-face's 3x3 (32 filters) as a direct
