@@ -1277,32 +1277,32 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_bdp_kernel(const Co
   const __amdgpu_buffer_rsrc_t res_rsrc = make_rsrc(a.res, a.res ? (uint32_t)((int64_t)a.M * a.Cout * 4) : 0u);
   const __amdgpu_buffer_rsrc_t y_rsrc = make_rsrc(a.y, a.y ? (uint32_t)((int64_t)a.M * a.Cout * 4) : 0u);
   const __amdgpu_buffer_rsrc_t y2_rsrc = make_rsrc(a.y2, a.y2 ? (uint32_t)((int64_t)a.M * a.Cout * 4) : 0u);
-  auto chunk_row = [&](int r) -> int {                     // output pixel (linear index) of accumulator register r
-    const int rl = erow_l + (r & 3) + 8 * (r >> 2);
-    return TILE2D ? p_row0 + (rl >> 3) * a.W + (rl & 7) : p_row0 + rl;
-  };
+  // Accumulator register r of a lane is tile row erow_l + (r & 3) + 8 (r >> 2): relative to the lane's register 0 that is
+  // a block-uniform number of output rows, so a register's byte offset is the lane's base offset (set at hand-over, OOB
+  // for a column beyond Cout) plus a scalar -- one vector add and one select per access.
+  uint32_t p_off = OOB, voff[2];
+  auto reg_rows = [&](int r) -> int { return TILE2D ? (r >> 2) * a.W + (r & 3) : 8 * (r >> 2) + (r & 3); };
   // Chunk j = accumulator registers 2j, 2j + 1, kept in LDS (in registers the set costs 16 VGPRs the K loop does not have:
   // 44-64 spilled; a switch over static register indices made the compiler clone the K loop): pre() requests the two
   // values and the two shortcut values before the step's MFMAs, post() uses them after.
   auto retire_pre = [&](int j) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const int row = chunk_row(2 * j + q);
-      const uint32_t off = (uint32_t)(row * a.Cout + pcol) * 4u;
-      rres[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(res_rsrc, row < row_lim ? off : OOB, 0, 0));
+      const int dr = reg_rows(2 * j + q);
+      const bool ok = p_off != OOB && (TILE2D || p_row0 + dr < row_lim);      // p_row0: the lane's register-0 row
+      voff[q] = ok ? p_off + (uint32_t)(dr * a.Cout) * 4u : OOB;
+      rres[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(res_rsrc, voff[q], 0, 0));
       av[q] = accp[(2 * j + q) * T::NT];
     }
   };
   auto retire_post = [&](int j) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const int row = chunk_row(2 * j + q);
       const float v = fmaf(av[q], sc, sh);
       const float t = (v >= 0.f ? v : v * sl) + rres[q];
       const float u = fmaf(t, sc2, sh2);
-      const uint32_t o = row < row_lim ? (uint32_t)(row * a.Cout + pcol) * 4u : OOB;
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, t), y_rsrc, o, 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, u >= 0.f ? u : u * sl2), y2_rsrc, o, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, t), y_rsrc, voff[q], 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, u >= 0.f ? u : u * sl2), y2_rsrc, voff[q], 0, 0);
     }
   };
   auto hook_pre = [&]() {
@@ -1416,12 +1416,14 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_bdp_kernel(const Co
       pcol = n0 + ecol_l;
       if constexpr (TILE2D) {
         int n, h0, w0;
-        p_row0 = tile2d_pix0(a, m0, n, h0, w0);
+        const int pix0 = tile2d_pix0(a, m0, n, h0, w0);
+        p_row0 = pix0 + (erow_l >> 3) * a.W + (erow_l & 7);      // erow_l = 32 wr + 4 h: the lane's register-0 pixel
       } else {
-        p_row0 = m0;
+        p_row0 = m0 + erow_l;
       }
+      row_lim = a.M;
       if (pcol < a.Cout) {
-        row_lim = a.M;
+        p_off = (uint32_t)(p_row0 * a.Cout + pcol) * 4u;
         sc = a.scale ? a.scale[pcol] : 1.f;
         sh = a.shift ? a.shift[pcol] : 0.f;
         sc2 = a.scale2 ? a.scale2[pcol] : 1.f;
@@ -1429,7 +1431,7 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_bdp_kernel(const Co
         sl = a.act == ACT_RELU ? 0.f : (a.act == ACT_PRELU ? (a.alpha ? a.alpha[pcol] : 0.f) : 1.f);
         sl2 = a.act2 == ACT_RELU ? 0.f : (a.act2 == ACT_PRELU ? (a.alpha2 ? a.alpha2[pcol] : 0.f) : 1.f);
       } else {
-        row_lim = 0;
+        p_off = OOB;
       }
       p_next = 0;
     }
