@@ -1,4 +1,5 @@
-"""A small reader for Keras HDF5 weight files (``model.save_weights('x.h5')``), in pure Python + NumPy.
+"""A small reader -- and, at the end of the file, writer -- for Keras HDF5 weight files (``model.save_weights('x.h5')``),
+in pure Python + NumPy.
 
 The reference loads its models through Keras (``model.load_weights(path.h5)``: api.py:87,
 networks/inceptionv3.py:79-82), so a drop-in has to read those files; ``h5py`` is used when it is importable, and this
@@ -316,3 +317,167 @@ def _collect(g, read):
             arr = np.ascontiguousarray(read(lg, wname), dtype=np.float32)
             out[wname.rsplit(':', 1)[0]] = arr
     return out
+
+
+# ----------------------------------------------------------------------------------------------------- writer
+# The counterpart for ``model.save_weights('x.h5')`` (networks/inceptionv3.py:84-88 of the reference) where h5py is
+# not installed: the same subset of the format, laid out the way libhdf5 1.8/1.10 lays out a file written with
+# default settings -- superblock 0, old-style groups (version-1 B-tree over symbol-table nodes of up to 2 * 4 entries,
+# up to 2 * 16 children per B-tree node, names in a local heap), version-1 object headers, contiguous little-endian
+# float32 datasets, attributes holding fixed-length NUL-padded strings.  tests/test_h5lite.py reads such files back
+# with this module's reader AND with the real HDF5 library (h5py under /opt/conda, where present).
+_LEAF_K, _NODE_K = 4, 16
+
+
+def _pad8(b):
+    return b + b'\x00' * (-len(b) % 8)
+
+
+def _dt_float32():
+    # class 1 (floating point) version 1; little-endian, msb-implied mantissa; sign bit 31; 32-bit precision,
+    # exponent at 23 (8 bits, bias 127), mantissa at 0 (23 bits)
+    return bytes([0x11, 0x20, 0x1F, 0x00]) + struct.pack('<I', 4) + struct.pack('<HHBBBBI', 0, 32, 23, 8, 0, 23, 127)
+
+
+def _dt_string(n):
+    # class 3 (string) version 1; NUL-padded, ASCII
+    return bytes([0x13, 0x01, 0x00, 0x00]) + struct.pack('<I', n)
+
+
+def _dataspace_msg(shape):
+    return bytes([1, len(shape), 0, 0, 0, 0, 0, 0]) + b''.join(struct.pack('<Q', int(d)) for d in shape)
+
+
+def _message(mtype, body):
+    body = _pad8(body)
+    if len(body) > 0xFFFF:
+        raise H5Error('object-header message of %d bytes exceeds the 64 KB limit of the format (Keras splits its name '
+                      'lists into layer_names0, layer_names1, ... beyond it; not needed by this package\'s models)' % len(body))
+    return struct.pack('<HHB3x', mtype, len(body), 0) + body
+
+
+def _attribute_msg(name, values):
+    """Attribute holding a fixed-length string (scalar, ``bytes``) or a 1-D array of them (list of ``bytes``)."""
+    nm = name.encode('utf-8') + b'\x00'
+    if isinstance(values, bytes):
+        width, shape, data = max(len(values), 1), (), values
+        data = data.ljust(width, b'\x00')
+    else:
+        width = max([len(v) for v in values] + [1])
+        shape, data = (len(values),), b''.join(v.ljust(width, b'\x00') for v in values)
+    dt, ds = _dt_string(width), _dataspace_msg(shape)
+    body = struct.pack('<BxHHH', 1, len(nm), len(dt), len(ds)) + _pad8(nm) + _pad8(dt) + _pad8(ds) + data
+    return _message(0x0C, body)
+
+
+def _object_header(messages):
+    body = b''.join(messages)
+    return struct.pack('<BxHII4x', 1, len(messages), 1, len(body)) + body
+
+
+class _Writer:
+    def __init__(self):
+        self.buf = bytearray(96)                             # the superblock goes here at the end
+
+    def alloc(self, data):
+        self.buf += b'\x00' * (-len(self.buf) % 8)
+        addr = len(self.buf)
+        self.buf += data
+        return addr
+
+    def dataset(self, arr):
+        shape = np.shape(arr)                                # (ascontiguousarray would turn a scalar into shape (1,))
+        arr = np.ascontiguousarray(arr, dtype='<f4')
+        raw = self.alloc(arr.tobytes()) if arr.size else UNDEF
+        layout = struct.pack('<BBQQ', 3, 1, raw, arr.nbytes)             # version 3, contiguous
+        return self.alloc(_object_header([_message(0x01, _dataspace_msg(shape)), _message(0x03, _dt_float32()),
+                                          _message(0x08, layout)]))
+
+    def group(self, links, attrs=()):
+        """links: {name: object-header address}; returns (header address, B-tree address, heap address)."""
+        names = sorted(links, key=lambda s: s.encode('utf-8'))
+        heap, offs = bytearray(b'\x00' * 8), {}              # offset 0: the empty string (the B-tree's first key)
+        for n in names:
+            offs[n] = len(heap)
+            heap += _pad8(n.encode('utf-8') + b'\x00')
+        data_addr = self.alloc(bytes(heap))
+        heap_addr = self.alloc(b'HEAP' + struct.pack('<B3xQQQ', 0, len(heap), 1, data_addr))   # free list: none (1)
+        # symbol-table nodes of up to 2 * _LEAF_K entries
+        children = []                                        # (address, heap offset of the largest name below it)
+        per = 2 * _LEAF_K
+        for i in range(0, max(len(names), 1), per):
+            part = names[i:i + per]
+            node = b'SNOD' + struct.pack('<BxH', 1, len(part))
+            for n in part:
+                node += struct.pack('<QQII16x', offs[n], links[n], 0, 0)
+            node += b'\x00' * (40 * (per - len(part)))
+            children.append((self.alloc(node), offs[part[-1]] if part else 0))
+        level = 0
+        while True:                                          # B-tree levels until one node is left
+            nodes, fan = [], 2 * _NODE_K
+            for i in range(0, len(children), fan):
+                part = children[i:i + fan]
+                first_key = 0 if i == 0 else children[i - 1][1]
+                body = struct.pack('<Q', first_key)
+                for addr, key in part:
+                    body += struct.pack('<QQ', addr, key)
+                body += b'\x00' * (16 * (fan - len(part)))
+                nodes.append([b'TREE' + struct.pack('<BBH', 0, level, len(part)), body, part[-1][1]])
+            addrs = []
+            for j, (head, body, _) in enumerate(nodes):      # siblings are contiguous: their addresses are known up front
+                self.buf += b'\x00' * (-len(self.buf) % 8)
+                base, size = len(self.buf), len(head) + 16 + len(body)
+                left = base - size if j > 0 else UNDEF
+                right = base + size if j + 1 < len(nodes) else UNDEF
+                addrs.append(self.alloc(head + struct.pack('<QQ', left, right) + body))
+            children = [(a, n[2]) for a, n in zip(addrs, nodes)]
+            if len(children) == 1:
+                break
+            level += 1
+        btree = children[0][0]
+        header = self.alloc(_object_header([_message(0x11, struct.pack('<QQ', btree, heap_addr))] + list(attrs)))
+        return header, btree, heap_addr
+
+    def finish(self, root):
+        header, btree, heap = root
+        sb = SIGNATURE + bytes([0, 0, 0, 0, 0, 8, 8, 0]) + struct.pack('<HHI', _LEAF_K, _NODE_K, 0)
+        sb += struct.pack('<QQQQ', 0, UNDEF, len(self.buf), UNDEF)
+        sb += struct.pack('<QQII', 0, header, 1, 0) + struct.pack('<QQ', btree, heap)   # root entry, cached B-tree + heap
+        assert len(sb) == 96
+        self.buf[0:96] = sb
+        return bytes(self.buf)
+
+
+def write_keras_weights(path, params):
+    """Writes ``{'layer/.../weight': ndarray}`` as a Keras ``save_weights`` file: one group per layer in first-seen
+    order (``layer_names``), inside it the datasets ``<layer>/<weight>:0`` (``weight_names``), float32."""
+    by_layer = {}
+    for k, v in params.items():
+        layer, w = k.rsplit('/', 1)
+        by_layer.setdefault(layer, []).append((w, v))
+    w = _Writer()
+
+    def tree(entries):
+        """entries: {path tuple: ndarray} -> links of one group level, built bottom-up."""
+        here, below = {}, {}
+        for path, arr in entries.items():
+            if len(path) == 1:
+                here[path[0]] = w.dataset(arr)
+            else:
+                below.setdefault(path[0], {})[path[1:]] = arr
+        for name, sub in below.items():
+            here[name] = w.group(tree(sub))[0]
+        return here
+
+    layers = {}
+    for layer, ws in by_layer.items():
+        wnames = ['%s/%s:0' % (layer, n) for n, _ in ws]
+        links = tree({tuple(p.split('/')): arr for p, (_, arr) in zip(wnames, ws)})
+        layers[layer] = w.group(links, [_attribute_msg('weight_names', [n.encode('utf-8') for n in wnames])])[0]
+    for layer in by_layer:
+        if '/' in layer:
+            raise H5Error("layer name '%s' contains '/': not representable as one Keras layer group" % layer)
+    root = w.group(layers, [_attribute_msg('layer_names', [n.encode('utf-8') for n in by_layer]),
+                            _attribute_msg('backend', b'tensorflow')])
+    with open(path, 'wb') as fh:
+        fh.write(w.finish(root))

@@ -103,12 +103,7 @@ class DifEmbedder:
 
     def save_weights(self, path):
         if str(path).endswith(('.h5', '.hdf5')):
-            try:
-                import h5py  # noqa: F401
-            except ImportError:
-                raise ValueError('writing Keras HDF5 needs h5py, which is not installed here; save as .npz '
-                                 '(load_weights reads both)')
-            W.save_keras_h5(path, self.get_weights())
+            W.save_keras_h5(path, self.get_weights())           # Keras save_weights layout (h5py, or networks/h5lite.py)
             return
         W.save_npz(path, self.get_weights())
 

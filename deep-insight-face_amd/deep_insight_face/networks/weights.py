@@ -53,8 +53,14 @@ def load_npz(path):
 
 
 def save_keras_h5(path, params):
-    """Keras ``save_weights`` layout (needs h5py): one group per layer, ``weight_names`` / ``layer_names`` attributes."""
-    import h5py
+    """Keras ``save_weights`` layout: one group per layer, ``weight_names`` / ``layer_names`` attributes.  Through h5py
+    where it is installed, otherwise through the pure-Python writer of networks/h5lite.py (same layout, float32)."""
+    try:
+        import h5py
+    except ImportError:
+        from . import h5lite
+        h5lite.write_keras_weights(path, params)
+        return
     by_layer = {}
     for k, v in params.items():
         layer, w = k.rsplit('/', 1)

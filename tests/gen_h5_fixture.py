@@ -2,6 +2,8 @@
 
     /opt/conda/bin/python3.9 tests/gen_h5_fixture.py tiny tests/golden/keras_tiny.h5
     /opt/conda/bin/python3.9 tests/gen_h5_fixture.py npz <weights.npz> <out.h5>
+    /opt/conda/bin/python3.9 tests/gen_h5_fixture.py read <in.h5> <out.npz>     # the other way: the real library reads a
+                                                                                 # file written by h5lite's writer
 
 (h5py is absent from the image's main interpreter but present under /opt/conda; the product never needs it: it reads
 these files with deep_insight_face/networks/h5lite.py.)  The layout is what Keras' ``save_weights`` writes
@@ -53,8 +55,25 @@ def from_npz(npz, out):
     write(out, sorted(by_layer.items()))
 
 
+def to_npz(h5, out):
+    """Reads a Keras-layout file the way Keras' loader does (layer_names / weight_names attributes) with the real library."""
+    got = {}
+    with h5py.File(h5, 'r') as f:
+        assert f.attrs['backend'] in (b'tensorflow', 'tensorflow')
+        for layer in f.attrs['layer_names']:
+            g = f[layer.decode() if isinstance(layer, bytes) else layer]
+            for wn in g.attrs['weight_names']:
+                wn = wn.decode() if isinstance(wn, bytes) else wn
+                got[wn.rsplit(':', 1)[0].replace('/', '::')] = np.asarray(g[wn])
+        n_links = []
+        f.visit(n_links.append)                                     # walks every group through the library's B-tree code
+    np.savez(out, n_links=np.array(len(n_links)), **got)
+
+
 if __name__ == '__main__':
     if sys.argv[1] == 'tiny':
         tiny(sys.argv[2])
+    elif sys.argv[1] == 'read':
+        to_npz(sys.argv[2], sys.argv[3])
     else:
         from_npz(sys.argv[2], sys.argv[3])

@@ -174,6 +174,14 @@ def test_weights_roundtrip(cuda, tmp_path):
     assert np.array_equal(other.predict_on_batch(x), a)
     with pytest.raises(ValueError):
         other.set_weights({k: v for k, v in p.items() if 'post_bn' not in k})
+    # the reference's own container: model.save_weights('x.h5') / load_weights('x.h5') (inceptionv3.py:79-88), written
+    # and read without h5py on this image (networks/h5lite.py)
+    h5 = str(tmp_path / 'w.h5')
+    model.save_weights(h5)
+    third = DifEmbedder('resnet', 'v1', 128, (112, 112, 3), max_batch=2)
+    third.load_weights(h5)
+    assert np.array_equal(third.predict_on_batch(x), a)
+    third.close()
     model.close()
     other.close()
 
