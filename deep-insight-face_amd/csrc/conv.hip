@@ -1631,6 +1631,13 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
       if (bd && conv_bdp_ok(a)) return launch_conv_bdp<T, 6>(a, st);
       return bd ? launch_conv_pre<T, false, false, 16>(a, st) : launch_conv_pre<T, false, false, 6>(a, st);
     }
+    // the deferred-epilogue patch kernel before the pipelined (gather) one: with very many tiles (batch 512 on one lane)
+    // the 128-channel 28x28 layers qualify for both
+    if (!use_dma && bd && !pw && conv_bdp_ok(a)) {
+      const int emax = patch_applies(a);
+      if (emax == PATCH_EMAX_S) return launch_conv_bdp<T, 3>(a, st);
+      if (emax == PATCH_EMAX_L) return launch_conv_bdp<T, 5>(a, st);
+    }
     if (!use_dma && a.Cin % 4 == 0 && pipe_applies(a, tiles, a.Kpad / BK, slots)) {
       // pointwise layers retire the previous tile four chunks per K-step, i.e. within the first two
       // steps (measured best for every K: 2 steps +16 %, 8 steps +5 % over one chunk per step); the
