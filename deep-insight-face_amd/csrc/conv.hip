@@ -576,15 +576,21 @@ __device__ __forceinline__ void gemm_mainloop_patch_bd(const PA& pa, const ConvA
     const uint32_t e = (uint32_t)(pa.base[0] + eoff);
     return (e << 7) | ((l0x ^ ((e >> 1) & 7u)) << 4);
   };
-  // one half-step: eight MFMAs on the A fragments of half s (read from the patch here) and the B fragments in b
-  auto half = [&](uint32_t a0, int s, const f32x4 (&b)[2]) {
-    const f32x4 fa0 = *reinterpret_cast<const f32x4*>(patch_b + (a0 ^ (uint32_t)(64 * s)));
-    const f32x4 fa1 = *reinterpret_cast<const f32x4*>(patch_b + (a0 ^ (uint32_t)(64 * s + 16)));
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[t], b[0][t], acc[0][0], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[t], b[1][t], acc[0][0], 0, 0, 0);
+  // A fragments are read one half-step AHEAD of their MFMAs, into two register sets: fa = half 0 of the coming step,
+  // fn = half 1 of the current one (the fragment of a step's first half is requested under the previous step's second half)
+  auto read_frag = [&](uint32_t a0, int s, f32x4 (&f)[2]) {
+    f[0] = *reinterpret_cast<const f32x4*>(patch_b + (a0 ^ (uint32_t)(64 * s)));
+    f[1] = *reinterpret_cast<const f32x4*>(patch_b + (a0 ^ (uint32_t)(64 * s + 16)));
   };
+  auto mfma8 = [&](const f32x4 (&f)[2], const f32x4 (&b)[2]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[0][t], b[0][t], acc[0][0], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[1][t], b[1][t], acc[0][0], 0, 0, 0);
+  };
+  f32x4 fa[2], fn[2];
+  uint32_t a0 = frag_addr();
+  read_frag(a0, 0, fa);
   int ks = kbeg;
   for (; ks + 1 < kend; ++ks) {
     bload(ks, 1, bB);                                      // lands under the first half's MFMAs
@@ -593,20 +599,25 @@ __device__ __forceinline__ void gemm_mainloop_patch_bd(const PA& pa, const ConvA
       pf_issued = true;
     }
     pre();
-    const uint32_t a0 = frag_addr();
+    read_frag(a0, 1, fn);
     __builtin_amdgcn_sched_barrier(0);
-    half(a0, 0, bA);
+    mfma8(fa, bA);
     bload(ks + 1, 0, bA);                                  // lands under the second half's MFMAs
-    __builtin_amdgcn_sched_barrier(0);
-    half(a0, 1, bB);
-    post();
     if (++kw == 3) {
       kw = 0;
       eoff += pa.WP - 2;
     } else {
       ++eoff;
     }
-    if (++tap == 9) {
+    const bool swap = ++tap == 9;
+    if (!swap) {                                           // the next step reads the same patch: its first half now
+      a0 = frag_addr();
+      read_frag(a0, 0, fa);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma8(fn, bB);
+    post();
+    if (swap) {
       tap = 0;
       eoff = 0;
       ++cb;
@@ -614,14 +625,16 @@ __device__ __forceinline__ void gemm_mainloop_patch_bd(const PA& pa, const ConvA
       pa.store(patch, pr);
       pf_issued = false;
       __syncthreads();
+      a0 = frag_addr();
+      read_frag(a0, 0, fa);
     }
   }
   bload(ks, 1, bB);
   tail();
   pre();
-  const uint32_t a0 = frag_addr();
-  half(a0, 0, bA);
-  half(a0, 1, bB);
+  read_frag(a0, 1, fn);
+  mfma8(fa, bA);
+  mfma8(fn, bB);
   post();
   __syncthreads();
 }
