@@ -84,7 +84,7 @@ def measured_traffic(workload, batch):
     """HBM bytes per forward of the conv kernels from the committed rocprofv3 PMC passes
     (FETCH_SIZE doubled + WRITE_SIZE, tools/pmc_traffic.py).  Counters cannot be read from
     inside the process, so this is the profile of the same command, or None."""
-    for rnd in ('r02', 'r01'):
+    for rnd in ('r03', 'r02', 'r01'):
         path = os.path.join(ROOT, 'profiles', '%s_%s_b%d_hbm_traffic.json' % (rnd, workload, batch))
         if os.path.exists(path):
             with open(path) as fh:
@@ -259,6 +259,25 @@ def cpu_baseline_frames(gallery_rows, det_params, n_frames=4):
                       'decode/NMS/crop + reference-formula match vs %d rows, %.2fs' % (n_frames, cores, gallery_rows, dt)}
 
 
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher: this process becomes the parent of one
+    torch.distributed.run job (one child per GPU) and only relays its output and exit code.  It has made
+    no HIP call (importing torch does not initialise the GPU), and nothing that has is ever re-exec'd: the
+    ranks are fresh child processes."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault('OMP_NUM_THREADS', '4')
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -276,9 +295,9 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))        # before any GPU call in this process
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run (one process per GPU)' % args.gpus)
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit('bench.py needs a HIP device: the hot path has no CPU fallback')
@@ -318,16 +337,22 @@ def main():
     model.set_input_transform(scale=1 / 255.)                 # predictions.py:154 `* rescale`, fused
     # every embedding forward this process runs, by batch size (tools/check_profiles.py divides profiler totals by it)
     forwards = {}
-    _embed = model.embed
+    _embed, _embed_into = model.embed, model.embed_into
 
     def _counted_embed(x, *a, **k):
         forwards[int(x.shape[0])] = forwards.get(int(x.shape[0]), 0) + 1
         return _embed(x, *a, **k)
-    model.embed = _counted_embed
+
+    def _counted_embed_into(x, *a, **k):
+        forwards[int(x.shape[0])] = forwards.get(int(x.shape[0]), 0) + 1
+        return _embed_into(x, *a, **k)
+    model.embed, model.embed_into = _counted_embed, _counted_embed_into
     lo, hi = shard_bounds(gallery_rows, world, rank)
     gal_full = synthetic_gallery(gallery_rows, 512, 7, 'cpu')
-    shard = ShardedGallery(gal_full[lo:hi].to(dev), lo)
+    shard_rows = gal_full[lo:hi].to(dev)                      # kept: the self-check after the timed region plants rows
+    shard = ShardedGallery(shard_rows, lo)
     del gal_full
+    emb_buf = torch.empty((batch, 512), dtype=torch.float32, device=dev)   # the serving loop allocates nothing per step
     arc = None
     if args.workload == 'r100_arc':
         from deep_insight_face.networks.arcmargin import ArcMarginHead
@@ -358,10 +383,10 @@ def main():
             e_det = torch.cuda.Event(enable_timing=True)
             e_det.record()
             det_ms.append(e_det)
-        emb = model.embed(faces)
+        emb = model.embed_into(faces, emb_buf)
         if i is not None:
             ev[i][1].record()
-        idx, d = shard.match(emb, 1)
+        idx, d = shard.match(emb, 1, copy=False)
         if i is not None:
             ev[i][2].record()
         return idx, d
@@ -371,12 +396,12 @@ def main():
             return step_frames(i)
         if i is not None:
             ev[i][0].record()
-        emb = model.embed(crops)
+        emb = model.embed_into(crops, emb_buf)
         if i is not None:
             ev[i][1].record()
         if arc is not None:
             arc.logits(emb, arc_labels)
-        idx, d = shard.match(emb, 1)
+        idx, d = shard.match(emb, 1, copy=False)
         if i is not None:
             ev[i][2].record()
         return idx, d
@@ -399,6 +424,26 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # Self-check, after the timed region and never inside it: enrol 8 of this step's probes at known rows
+    # spread over the whole (sharded) gallery, run one more step through the same code path and require every
+    # rank to name exactly those rows.  A throughput line whose step computed something else fails here.
+    B_all = world * batch
+    emb_all = shard.all_gather_embeddings(emb_buf).clone()
+    probe_ids = [int(v) for v in np.linspace(0, B_all - 1, 8).round()]
+    plant_rows = [int(v) for v in np.linspace(0, gallery_rows - 1, 8).round()]
+    for pid, row in zip(probe_ids, plant_rows):
+        if lo <= row < hi:
+            shard_rows[row - lo] = emb_all[pid]
+    shard.gallery.set(shard_rows, lo)
+    idx_v, d_v = step()
+    torch.cuda.synchronize()
+    got = [int(idx_v[pid]) for pid in probe_ids]
+    dv = d_v[probe_ids].cpu().numpy()
+    verified = got == plant_rows and bool(np.all(np.isnan(dv) | (dv < 2e-3)))   # NaN: similarity rounded above 1, as in the reference
+    if not verified:
+        raise SystemExit('bench.py self-check FAILED on rank %d: planted rows %s, matched %s (dist %s)'
+                         % (rank, plant_rows, got, dv.tolist()))
 
     embed_ms = float(np.mean([ev[i][0].elapsed_time(ev[i][1]) for i in range(args.steps)]))
     match_ms = float(np.mean([ev[i][1].elapsed_time(ev[i][2]) for i in range(args.steps)]))
@@ -453,6 +498,7 @@ def main():
             'vs_baseline': None,
             'dtype': 'f32' if compute == 'f32' else 'bf16x3 (f32 operands split into 3 bf16 terms, 6 MFMA products, f32 accumulate)',
             'data': 'synthetic (uint8 crops seed 1234, He-normal weights seed 2024, unit-norm gallery seed 7)',
+            'verified': verified,       # after the timed region: 8 planted enrolments found at their rows by one more step
             'config': {'workload': desc, 'arch': arch, 'head': head, 'batch_per_gpu': batch,
                        'global_batch': world * batch, 'gallery_rows': gallery_rows,
                        'gallery_rows_per_gpu': hi - lo, 'emd': 512, 'metric': 'cosine',

@@ -76,7 +76,8 @@ int dif_gallery_destroy(dif_gallery* h) {
   if (g.sq) (void)hipFree(g.sq);
   if (g.ninv) (void)hipFree(g.ninv);
   for (void* p : {(void*)g.part_key, (void*)g.part_cnt, (void*)g.part_idx, (void*)g.eps, (void*)g.best,
-                  (void*)g.best_dist, (void*)g.flagged, (void*)g.nflag, (void*)g.sqmax_bits})
+                  (void*)g.best_dist, (void*)g.flagged, (void*)g.nflag, (void*)g.sqmax_bits, (void*)g.hi,
+                  (void*)g.pcls, (void*)g.anti_cnt, (void*)g.anti_idx, (void*)g.flags})
     if (p) (void)hipFree(p);
   delete h;
   return 0;
@@ -109,6 +110,15 @@ int dif_gallery_set(dif_gallery* h, const float* rows_dev, int64_t n, int64_t in
 }
 
 int64_t dif_gallery_size(const dif_gallery* h) { return h ? h->g.n : 0; }
+
+int dif_gallery_set_option(dif_gallery* h, const char* key, int value) {
+  if (!h || !key) return set_error("dif_gallery_set_option: null argument");
+  if (std::string(key) == "clamp_nan") {
+    h->g.clamp_nan = value != 0;
+    return 0;
+  }
+  return set_error("dif_gallery_set_option: unknown key '%s'", key);
+}
 
 int dif_match(dif_gallery* h, const float* probes_dev, int n, int metric, int64_t* idx_out_dev,
               float* dist_out_dev, float* key_out_dev, void* stream) {

@@ -35,8 +35,14 @@ struct Gallery {
   float* best_dist = nullptr;
   int* flagged = nullptr;
   size_t probe_cap = 0;
+  float* hi = nullptr;             // per probe: key above which a row may be anti-parallel beyond -1 (metric 1)
+  int* pcls = nullptr;             // per probe: 1 = |q|^2 outside the filter's range, classified by the finish stage
+  int* anti_cnt = nullptr;         // per probe: rows whose key reached hi, and up to KANTI of their indices
+  int* anti_idx = nullptr;
   int* nflag = nullptr;            // number of probes sent to the exact search in the current call
-  unsigned* sqmax_bits = nullptr;  // bits of max |g|^2 over the rows
+  unsigned* sqmax_bits = nullptr;  // bits of max |g|^2 over the rows the metric-0 filter sees
+  struct GalleryFlags* flags = nullptr;   // rows the filter cannot rank (csrc/match.hip), found by gallery_norms
+  bool clamp_nan = false;          // report distance 0 / 1 instead of the reference's NaN (dif_gallery_set_option)
 };
 
 int gallery_norms(Gallery* g, hipStream_t st);

@@ -81,16 +81,19 @@ __global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restric
 // boxes: [N][4] = left, top, right, bottom in frame pixels (as detector/run.py:114 returns them)
 __global__ __launch_bounds__(256) void crop_resize_kernel(const uint8_t* __restrict__ frames, int N, int H, int W,
                                                           const float* __restrict__ boxes, float margin,
-                                                          uint8_t* __restrict__ out, int S) {
-  const int64_t total = (int64_t)N * S * S;
+                                                          uint8_t* __restrict__ out, int SW, int SH) {
+  const int64_t total = (int64_t)N * SW * SH;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int x = (int)(i % S);
-    const int y = (int)((i / S) % S);
-    const int64_t n = i / ((int64_t)S * S);
-    // filter_bounding_box (run.py:76-80): margin/2 on every side, clamped, truncated to int32
-    const float* b = boxes + n * 4;
-    int l = (int)fmaxf(b[0] - margin / 2, 0.f), t = (int)fmaxf(b[1] - margin / 2, 0.f);
-    int r = (int)fminf(b[2] + margin / 2, (float)W), bt = (int)fminf(b[3] + margin / 2, (float)H);
+    const int x = (int)(i % SW);
+    const int y = (int)((i / SW) % SH);
+    const int64_t n = i / ((int64_t)SW * SH);
+    // filter_bounding_box (run.py:76-80): margin/2 on every side, clamped, truncated to int32;
+    // boxes == nullptr: the whole image (dif_area_resize)
+    const float whole[4] = {0.f, 0.f, (float)W, (float)H};
+    const float* b = boxes ? boxes + n * 4 : whole;
+    const float mg = boxes ? margin : 0.f;
+    int l = (int)fmaxf(b[0] - mg / 2, 0.f), t = (int)fmaxf(b[1] - mg / 2, 0.f);
+    int r = (int)fminf(b[2] + mg / 2, (float)W), bt = (int)fminf(b[3] + mg / 2, (float)H);
     uint8_t* o = out + i * 3;
     const int cw = r - l, ch = bt - t;
     const bool nodet = b[0] != b[0] || b[1] != b[1] || b[2] != b[2] || b[3] != b[3];   // NaN = no detection
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(256) void crop_resize_kernel(const uint8_t* __restr
       continue;
     }
     const uint8_t* img = frames + n * (int64_t)H * W * 3;
-    const float sx = (float)cw / S, sy = (float)ch / S;
+    const float sx = (float)cw / SW, sy = (float)ch / SH;
     float acc[3] = {0.f, 0.f, 0.f};
     {
       // cv2 INTER_AREA: the output pixel's footprint in the crop, source pixels weighted by the
@@ -155,7 +158,20 @@ int dif_crop_resize(const uint8_t* frames_dev, int n, int h, int w, const float*
   int64_t blocks = ((int64_t)n * size * size + 255) / 256;
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(crop_resize_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, frames_dev, n, h, w,
-                     boxes_ltrb_dev, margin, out_dev, size);
+                     boxes_ltrb_dev, margin, out_dev, size, size);
+  DIF_HIP(hipGetLastError());
+  return 0;
+}
+
+int dif_area_resize(const uint8_t* images_dev, int n, int h, int w, uint8_t* out_dev, int out_h, int out_w,
+                    void* stream) {
+  if (n < 0 || h <= 0 || w <= 0 || out_h <= 0 || out_w <= 0) return set_error("dif_area_resize: bad sizes");
+  if (n == 0) return 0;
+  if (!images_dev || !out_dev) return set_error("dif_area_resize: null pointer");
+  int64_t blocks = ((int64_t)n * out_h * out_w + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(crop_resize_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, images_dev, n, h, w,
+                     (const float*)nullptr, 0.f, out_dev, out_w, out_h);
   DIF_HIP(hipGetLastError());
   return 0;
 }

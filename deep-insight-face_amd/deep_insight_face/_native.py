@@ -40,10 +40,12 @@ SIGNATURES = {
                         c_void_p, c_void_p]),
     'dif_letterbox': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     'dif_crop_resize': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_int, c_void_p]),
+    'dif_area_resize': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     'dif_gallery_create': (c_int, [P(c_void_p), c_int]),
     'dif_gallery_destroy': (c_int, [c_void_p]),
     'dif_gallery_set': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     'dif_gallery_size': (c_int64, [c_void_p]),
+    'dif_gallery_set_option': (c_int, [c_void_p, c_char_p, c_int]),
     'dif_match': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dif_match_merge': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'dif_match_merge_packed': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -94,8 +94,13 @@ class DifEmbedder:
             spec = dict(self.param_spec())
             params = {}
             for name, a in h5lite.read_keras_weights(path).items():
-                if name in spec and a.shape != spec[name] and a.size == int(np.prod(spec[name])):
-                    a = a.reshape(spec[name])          # e.g. PReLU alpha saved as (1, 1, C) with shared spatial axes
+                if name in spec and tuple(a.shape) != tuple(spec[name]):
+                    # only singleton axes may differ (PReLU alpha saved as (1, 1, C) with shared spatial axes); a
+                    # kernel in another layout (OIHW vs HWIO, a transposed Dense) is refused, as Keras refuses it
+                    if tuple(d for d in a.shape if d != 1) != tuple(d for d in spec[name] if d != 1):
+                        raise ValueError('weight %s has shape %s in %s, expected %s'
+                                         % (name, tuple(a.shape), path, tuple(spec[name])))
+                    a = a.reshape(spec[name])
                 params[name] = a
             self.set_weights(params)
             return
@@ -175,6 +180,38 @@ class DifEmbedder:
         for s in range(0, n, self.max_batch):
             e = min(n, s + self.max_batch)
             N.check(N.lib.dif_net_embed(self._h, N.ptr(t[s:e]), e - s, layout, dtype, N.ptr(flat[s:e]),
+                                        N.stream_ptr()))
+        return out
+
+    def embed_into(self, x, out, layout=None):
+        """Allocation-free form for a serving loop: `x` a CUDA tensor [n <= max_batch, H, W, 3] or [n, 3, H, W],
+        uint8 or float32, contiguous; the embeddings are written into the caller's `out`, a contiguous float32
+        CUDA tensor [n, emd].  Nothing is converted or copied -- whatever the library could not read as it is
+        raises ValueError."""
+        dev = N.require_device()
+        self._finalize()
+        H, Wd, _ = self.input_shape
+        if not torch.is_tensor(x) or x.dim() != 4 or x.device != dev or not x.is_contiguous() \
+                or x.dtype not in (torch.uint8, torch.float32):
+            raise ValueError('embed_into: x must be a contiguous uint8 / float32 4-D tensor on %s' % dev)
+        if layout is None:
+            if tuple(x.shape[1:]) == (H, Wd, 3):
+                layout = N.LAYOUT_NHWC
+            elif tuple(x.shape[1:]) == (3, H, Wd):
+                layout = N.LAYOUT_NCHW
+            else:
+                raise ValueError('input %s matches neither [N,%d,%d,3] nor [N,3,%d,%d]'
+                                 % (tuple(x.shape), H, Wd, H, Wd))
+        n = x.shape[0]
+        per = int(np.prod(self.output_shape))
+        if len(self.output_shapes) > 1 or n > self.max_batch:
+            raise ValueError('embed_into: one output and at most max_batch = %d images per call' % self.max_batch)
+        if not torch.is_tensor(out) or out.dtype != torch.float32 or out.device != dev or not out.is_contiguous() \
+                or out.numel() != n * per or out.shape[0] != n:
+            raise ValueError('embed_into: out must be a contiguous float32 tensor [%d, %d] on %s' % (n, per, dev))
+        if n:
+            N.check(N.lib.dif_net_embed(self._h, N.ptr(x), n, layout,
+                                        N.DTYPE_U8 if x.dtype == torch.uint8 else N.DTYPE_F32, N.ptr(out),
                                         N.stream_ptr()))
         return out
 

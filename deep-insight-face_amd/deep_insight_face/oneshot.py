@@ -41,13 +41,31 @@ class Gallery:
     def __len__(self):
         return int(N.lib.dif_gallery_size(self._h))
 
+    def set_option(self, key, value):
+        """'clamp_nan': 1 reports distance 0 / 1 where the reference's distance is NaN (a similarity rounded
+        beyond +-1); the default 0 reports NaN like the reference.  The arg-min is unaffected."""
+        N.check(N.lib.dif_gallery_set_option(self._h, key.encode(), int(value)), ValueError)
+
     def match_into(self, probes, distance_metric, idx, dist, key=None):
         """Allocation-free form for a serving loop: `probes` [B, d] float32 CUDA, results written into the
         caller's CUDA tensors idx [B] int64, dist [B] float32 and (optional) key [B] float32 -- which may be
         slices of one packed buffer (see ShardedGallery)."""
         if distance_metric not in (0, 1):
             raise RuntimeError('Undefined distance metric %d' % distance_metric)
+        # the library reads `probes` as dense float32 [B, emd_size] and writes B results: anything else would be
+        # read out of bounds or reinterpreted silently, so it is refused here (no conversion: this form allocates nothing)
+        if not torch.is_tensor(probes) or probes.dim() != 2 or probes.shape[1] != self.emd_size:
+            raise ValueError('probes must be a [B, %d] tensor, got %s' % (
+                self.emd_size, tuple(probes.shape) if hasattr(probes, 'shape') else type(probes).__name__))
         B = probes.shape[0]
+        for name, t, dt in (('probes', probes, torch.float32), ('idx', idx, torch.int64), ('dist', dist, torch.float32),
+                            ('key', key, torch.float32)):
+            if t is None and name == 'key':
+                continue
+            if not torch.is_tensor(t) or t.dtype != dt or t.device != self._dev or not t.is_contiguous():
+                raise ValueError('match_into: %s must be a contiguous %s tensor on %s' % (name, dt, self._dev))
+            if name != 'probes' and (t.dim() != 1 or t.shape[0] != B):
+                raise ValueError('match_into: %s must have shape [%d], got %s' % (name, B, tuple(t.shape)))
         if B:
             if len(self) == 0:
                 raise ValueError('attempt to get argmin of an empty sequence')

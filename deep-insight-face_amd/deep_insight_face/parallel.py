@@ -83,14 +83,21 @@ class ShardedGallery:
         dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
         return out
 
-    def match(self, local_embeddings, distance_metric=1):
-        """Steps 2-5: returns (idx[R*b] int64 global, dist[R*b] float32), identical on every rank.  On the HIP
-        path nothing is allocated per step: the match writes its (key, dist, idx) straight into this rank's
-        record of one packed buffer, ONE all-gather moves the records, dif_match_merge_packed reduces them.
-        (The returned tensors are reused by the next call of the same shape.)"""
+    def match(self, local_embeddings, distance_metric=1, copy=True):
+        """Steps 2-5: returns (idx[R*b] int64 global, dist[R*b] float32), identical on every rank.
+        `local_embeddings`: [b, emd_size], NumPy or torch on any device / float dtype / strides (converted to a
+        dense float32 tensor on this rank's GPU, like Gallery.match; a wrong width raises ValueError).
+        On the HIP path the match writes its (key, dist, idx) straight into this rank's record of one packed,
+        preallocated buffer, ONE all-gather moves the records, dif_match_merge_packed reduces them.
+        copy=True (default) returns fresh tensors; copy=False returns the step buffers themselves, which the
+        NEXT call of the same shape overwrites -- the allocation-free form for a serving loop."""
         if self._match is not None:
             return self._match_injected(local_embeddings, distance_metric)
         from . import _native as N
+        local_embeddings, _ = N.to_device_f32(local_embeddings, self.gallery._dev)
+        if local_embeddings.dim() != 2 or local_embeddings.shape[1] != self.gallery.emd_size:
+            raise ValueError('embeddings must be [b, %d], got %s' % (self.gallery.emd_size,
+                                                                      tuple(local_embeddings.shape)))
         b, d = local_embeddings.shape
         key = (b, d, local_embeddings.device)
         buf = self._bufs.get(key)
@@ -101,11 +108,13 @@ class ShardedGallery:
         k, dd, ix = buf.record(B)
         if self.world == 1:
             self.gallery.match_into(probes, distance_metric, buf.out_idx, buf.out_dist)
-            return buf.out_idx, buf.out_dist
-        self.gallery.match_into(probes, distance_metric, ix, dd, k)
-        dist.all_gather_into_tensor(buf.packed.view(-1), buf.local, group=self.group)
-        N.check(N.lib.dif_match_merge_packed(N.ptr(buf.packed), self.world, B, N.ptr(buf.out_idx), N.ptr(buf.out_dist),
-                                             N.stream_ptr()))
+        else:
+            self.gallery.match_into(probes, distance_metric, ix, dd, k)
+            dist.all_gather_into_tensor(buf.packed.view(-1), buf.local, group=self.group)
+            N.check(N.lib.dif_match_merge_packed(N.ptr(buf.packed), self.world, B, N.ptr(buf.out_idx),
+                                                 N.ptr(buf.out_dist), N.stream_ptr()))
+        if copy:
+            return buf.out_idx.clone(), buf.out_dist.clone()
         return buf.out_idx, buf.out_dist
 
     def _match_injected(self, local_embeddings, distance_metric):

@@ -19,14 +19,26 @@ _VGG_MEAN_BGR = (103.939, 116.779, 123.68)   # keras.applications.imagenet_utils
 
 
 def _resize(image, size):
-    """cv2.resize(image, size, interpolation=Image.BICUBIC): PIL's BICUBIC constant (3) is
-    cv2.INTER_AREA.  Identity for crops already at the target size --
-    the case the hot path is specified for; other sizes go through PIL's box filter."""
+    """cv2.resize(image, size, interpolation=Image.BICUBIC) (predictions.py:93,154): PIL's BICUBIC
+    constant (3) is cv2.INTER_AREA, i.e. area-coverage resampling.  Identity for
+    crops already at the target size -- the case the hot path is specified for; other sizes are resampled
+    on the device by the library's area-coverage kernel (dif_area_resize, the one behind dif_crop_resize).
+    -> uint8 CUDA tensor [h, w, 3]."""
+    import torch
+    from . import _native as N
     w, h = int(size[0]), int(size[1])
-    if image.shape[0] == h and image.shape[1] == w:
-        return image
-    from PIL import Image
-    return np.asarray(Image.fromarray(image).resize((w, h), Image.BOX))
+    dev = N.require_device()
+    img = np.ascontiguousarray(image)
+    if img.ndim != 3 or img.shape[2] != 3:
+        raise ValueError('expected an [H, W, 3] image, got shape %s' % (img.shape,))
+    if img.shape[0] == h and img.shape[1] == w:
+        return torch.from_numpy(img).to(dev)
+    if img.dtype != np.uint8:
+        raise ValueError('an image of another size than %dx%d must be uint8 to be resized (got %s)' % (w, h, img.dtype))
+    src = torch.from_numpy(img).to(dev)
+    out = torch.empty((h, w, 3), dtype=torch.uint8, device=dev)
+    N.check(N.lib.dif_area_resize(N.ptr(src), 1, img.shape[0], img.shape[1], N.ptr(out), h, w, N.stream_ptr()))
+    return out
 
 
 @add_metaclass(ABCMeta)
@@ -53,7 +65,13 @@ class encoding_base:
         pass
 
     def _prep(self, images):
-        return np.stack([_resize(im, tuple(self.img_size)) for im in images])
+        import torch
+        return torch.stack([_resize(im, tuple(self.img_size)) for im in images])
+
+
+def _to_numpy(out):
+    """The wrappers return NumPy like the reference's predict_on_batch, whatever the batch was staged as."""
+    return out.cpu().numpy() if hasattr(out, 'cpu') else out
 
 
 def _saved_transform(model):
@@ -71,7 +89,7 @@ class TripletPrediction(encoding_base):
         saved = _saved_transform(self.emd_model)
         self.emd_model.set_input_transform(scale=rescale)
         try:
-            return self.emd_model.predict_on_batch(batch)
+            return _to_numpy(self.emd_model.predict_on_batch(batch))
         finally:
             self.emd_model.set_input_transform(*saved)        # the caller's transform, not the identity
 
@@ -104,7 +122,7 @@ class SiamesePrediction(encoding_base):
         saved = _saved_transform(self.emd_model)
         self.emd_model.set_input_transform(scale=rescale, bias=tuple(-m for m in _VGG_MEAN_BGR), bgr=True)
         try:
-            return self.emd_model.predict_on_batch(batch)
+            return _to_numpy(self.emd_model.predict_on_batch(batch))
         finally:
             self.emd_model.set_input_transform(*saved)
 

@@ -60,7 +60,7 @@ int dif_probe_mfma_clock(double* ghz_out, double* tflops_out, void* stream);
  * broadcast of a single row, which is how a probe is compared with a whole gallery
  * in the reference's terms).  Replaces evaluation/utility.py:52-66 `distance`
  * (and its twin :174-188).  metric other than 0/1 fails like the reference's
- * RuntimeError('Undefined distance metric %d'). */
+ * RuntimeError('Undefined distance metric %d').  NaN where the reference gives NaN. */
 int dif_pairwise(const float* e1_dev, int64_t n1, const float* e2_dev, int64_t n2, int d, int metric,
                  float* out_dev, void* stream);
 
@@ -101,6 +101,11 @@ int dif_nms(const float* boxes_dev, const float* scores_dev, int n_images, int n
 int dif_letterbox(const uint8_t* frames_dev, int n, int h, int w, uint8_t* out_dev, int size, void* stream);
 int dif_crop_resize(const uint8_t* frames_dev, int n, int h, int w, const float* boxes_ltrb_dev, float margin,
                     uint8_t* out_dev, int size, void* stream);
+/* dif_area_resize: whole images [n][h][w][3] -> [n][out_h][out_w][3] by the same area coverage: the
+ *   `cv2.resize(image, size, interpolation=Image.BICUBIC)` of predictions.py:93,154 (PIL's BICUBIC
+ *   constant 3 is cv2.INTER_AREA) for crops that are not at the embedder's input size yet. */
+int dif_area_resize(const uint8_t* images_dev, int n, int h, int w, uint8_t* out_dev, int out_h, int out_w,
+                    void* stream);
 
 /* ------------------------------------------------------------------ gallery + 1:N match
  * The reference has no 1:N entry point; the semantics are utility.distance broadcast
@@ -112,10 +117,15 @@ int dif_gallery_destroy(dif_gallery* g);
  * per-row norms; index_base = global index of row 0 (gallery row-sharded over ranks) */
 int dif_gallery_set(dif_gallery* g, const float* rows_dev, int64_t n, int64_t index_base, void* stream);
 int64_t dif_gallery_size(const dif_gallery* g);
+/* options.  "clamp_nan": 0 (default) dif_match reports NaN where the reference's distance is NaN; 1 reports the
+ * distance of the similarity clamped to [-1, 1] instead (0 for a similarity rounded above 1, 1 below -1).  The
+ * arg-min is the reference's either way. */
+int dif_gallery_set_option(dif_gallery* g, const char* key, int value);
 /* top-1 search of n probes [n][d]: idx_out_dev[n] = np.argmin over the reference's float32 distances
- * (int64 global index; first minimum; a row whose reference distance is NaN -- similarity rounded
- * above 1 -- ranks first, as in np.argmin), dist_out_dev[n] = that row's distance (similarity clamped
- * to [-1, 1], so 0 where the reference has NaN), key_out_dev[n] (optional, may be NULL) = the ranking
+ * (int64 global index; first minimum; a row whose reference distance is NaN ranks first, as in
+ * np.argmin: a similarity rounded beyond +-1, a zero-norm or non-finite gallery row or probe --
+ * utility.py:58-62 guards none of them), dist_out_dev[n] = that row's distance (NaN where the
+ * reference's is NaN unless "clamp_nan" is set), key_out_dev[n] (optional, may be NULL) = the ranking
  * key: the reference distance itself, -inf for NaN; comparable across gallery shards. */
 int dif_match(dif_gallery* g, const float* probes_dev, int n, int metric, int64_t* idx_out_dev,
               float* dist_out_dev, float* key_out_dev, void* stream);

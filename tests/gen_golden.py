@@ -97,7 +97,23 @@ def main():
             rec['nnan%d' % metric] = np.array(nnan, dtype=np.int32)       # rows whose reference distance is NaN (s > 1)
     np.savez(os.path.join(OUT, 'match_near_ties.npz'), **rec)
 
-    # 6. structure the reference holds as DATA (no TensorFlow needed to read it) ------
+    # 6. degenerate rows and probes: zero norms, non-finite elements, anti-parallel rows ---------------
+    rec = {}
+    with np.errstate(all='ignore'):
+        for name, probes, gallery in gi.match_degenerate_cases():
+            rec[name + '_sha'] = gi.digest(probes, gallery)
+            for metric in (0, 1):
+                idx, dmin = [], []
+                for q in probes:
+                    d = ref_utility.distance(q[None, :], gallery, metric)
+                    i = int(np.argmin(d))
+                    idx.append(i)
+                    dmin.append(d[i])
+                rec['%s_idx%d' % (name, metric)] = np.array(idx, dtype=np.int64)
+                rec['%s_dmin%d' % (name, metric)] = np.array(dmin, dtype=np.float32)
+    np.savez(os.path.join(OUT, 'match_degenerate.npz'), **rec)
+
+    # 7. structure the reference holds as DATA (no TensorFlow needed to read it) ------
     write_structure(os.path.join(OUT, 'structure.json'))
     print('wrote', sorted(os.listdir(OUT)))
 

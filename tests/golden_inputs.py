@@ -119,3 +119,92 @@ def match_near_tie_inputs(b=48, g=4096, seed=41):
     for r in slots[used:]:
         gal[r] = gal[r] * scale[r]
     return probes.astype(np.float32), gal.astype(np.float32)
+
+
+def match_degenerate_cases(g=4608, seed=77):
+    """Inputs the reference's distance has no guard for (evaluation/utility.py:58-62 divides by the norm
+    product and feeds arccos unclamped), so its answer is whatever IEEE arithmetic and np.argmin's
+    first-NaN rule give: zero-norm / tiny / huge / non-finite gallery rows at several positions, rows exactly
+    anti-parallel to a probe (similarity may round below -1), zero / tiny / huge / non-finite probes, an
+    all-zero gallery.  Returns [(name, probes [b, D], gallery [g, D])]; every gallery has >= 4096 rows."""
+    rng = np.random.default_rng(seed)
+    f32 = np.float32
+    cases = []
+
+    def base():
+        gal = _unit(rng.standard_normal((g, D)))
+        p, pick = probes_from(gal, 24, seed=int(rng.integers(1 << 30)))
+        p = (p * rng.uniform(0.5, 3.0, (24, 1))).astype(f32)
+        return gal, p
+
+    # 1. zero-norm rows at several positions (the first one after a few hundred ordinary rows)
+    gal, p = base()
+    gal[[417, 1500, 1501, 4000, g - 1]] = 0
+    cases.append(('zero_rows', p, gal))
+
+    # 2. zero-norm row at index 0 and in the last tile
+    gal, p = base()
+    gal[[0, g - 3]] = 0
+    cases.append(('zero_row_first', p, gal))
+
+    # 3. non-finite elements: +inf, -inf, NaN, a row with both; no zero rows
+    gal, p = base()
+    gal[900, 17] = np.inf
+    gal[3100, 400] = -np.inf
+    gal[2200, 5] = np.nan
+    gal[2201, [1, 2]] = [np.nan, np.inf]
+    gal[4500, 0] = np.inf
+    gal[4500, 1] = -np.inf
+    cases.append(('nonfinite_rows', p, gal))
+
+    # 4. NaN row first, inf rows later (metric 0: the NaN row wins; metric 1: the lowest of all of them)
+    gal, p = base()
+    gal[3000, 100] = np.nan
+    gal[1200, 7] = np.inf
+    cases.append(('nan_after_inf', p, gal))
+
+    # 5. tiny and huge rows that are ordinary for the reference: scaled copies of the probes' true neighbours
+    gal, p = base()
+    for k, (row, sc) in enumerate(((50, 1e-17), (700, 1e-18), (1300, 3e-16), (2600, 1e16), (3900, 4e17), (4400, 1e-16))):
+        gal[row] = (_unit(p[k][None])[0].astype(np.float64) * sc).astype(f32)
+    gal[2000] = (gal[2000].astype(np.float64) * 1e-25).astype(f32)      # squares underflow to 0: norm 0 -> NaN
+    gal[2500] = (gal[2500].astype(np.float64) * 1e19).astype(f32)       # squares sum to +inf: similarity 0
+    cases.append(('tiny_huge_rows', p, gal))
+    gal2 = gal.copy()
+    gal2[2000] = gal2[2001]
+    cases.append(('tiny_huge_rows_no_nan', p, gal2))
+
+    # 6. anti-parallel rows: g = -c q, so the similarity is -1 up to rounding and lands below -1 for some
+    gal, p = base()
+    pa = np.concatenate([p, _unit(rng.standard_normal((40, D))) * rng.uniform(0.3, 5.0, (40, 1)).astype(f32)]).astype(f32)
+    rows = rng.permutation(g)[:pa.shape[0]]
+    for k, r in enumerate(rows):
+        gal[r] = (-pa[k] * f32(rng.uniform(0.25, 4.0))).astype(f32)
+    cases.append(('antiparallel', pa, gal))
+
+    # 7. degenerate probes against an ordinary gallery (+ one zero row late, one inf row)
+    gal, p = base()
+    bad = p[:12].copy()
+    bad[0] = 0
+    bad[1, 3] = np.nan
+    bad[2, 9] = np.inf
+    bad[3, 9] = -np.inf
+    bad[4] = (bad[4].astype(np.float64) * 1e-25).astype(f32)            # |q|^2 underflows to 0
+    bad[5] = (bad[5].astype(np.float64) * 1e-17).astype(f32)            # tiny but valid
+    bad[6] = (bad[6].astype(np.float64) * 1e17).astype(f32)             # huge but valid
+    bad[7] = (bad[7].astype(np.float64) * 1e20).astype(f32)             # |q|^2 overflows to +inf
+    bad[8, :] = np.nan
+    bad[9] = 0
+    bad[9, 0] = 1e-30
+    bad[10, 100] = np.inf
+    bad[10, 101] = np.nan
+    probes = np.concatenate([bad, p[12:]]).astype(f32)
+    cases.append(('odd_probes', probes, gal))
+    gal2 = gal.copy()
+    gal2[3333] = 0
+    gal2[150, 9] = np.inf                                               # same position / sign as probe 2's inf
+    cases.append(('odd_probes_odd_rows', probes, gal2))
+
+    # 8. a gallery of nothing but zero rows (an unfilled shard)
+    cases.append(('all_zero_gallery', probes, np.zeros((4096, D), dtype=f32)))
+    return cases

@@ -51,11 +51,11 @@ def test_crop_resize_matches_oracle():
             assert (diff == 0).mean() > 0.98
 
 
-@pytest.mark.parametrize('nframes,h,w', [(4, 240, 320), (96, 480, 640)])
+@pytest.mark.parametrize('nframes,h,w', [(4, 240, 320), (96, 480, 640), (256, 480, 640)])
 def test_frame_pipeline_end_to_end(nframes, h, w):
     """Device pipeline == the same stages run one by one through the host-visible API; at 4 small frames and
-    at 96 frames of BASELINE configs[4]'s 640x480 (the detector then runs in chunks of its max_batch = 64,
-    the embedder splits its batch over two lanes...)."""
+    at 96 and at 256 frames (= BASELINE configs[4]'s batch) of its 640x480 (the detector then runs in chunks of
+    its max_batch = 64, the embedder splits its batch over two lanes...)."""
     from deep_insight_face import oneshot
     from deep_insight_face.detector import run as drun, yolov3 as yolo
     from deep_insight_face.networks.triplet import bottleneck_network

@@ -254,7 +254,7 @@ def test_reference_arithmetic_bit_exact(cuda, golden_dir):
         got1 = utility.distance(a, b, 1)
         ok = ~np.isnan(want1)
         assert np.abs(got1[ok].view(np.int32).astype(np.int64) - want1[ok].view(np.int32)).max() <= 4   # ulps
-        assert np.all(got1[~ok] == 0.0)                    # reference NaN (s > 1) <-> clamped to distance 0
+        assert np.all(np.isnan(got1[~ok]))                 # reference NaN (s > 1) <-> NaN
 
 
 @pytest.mark.parametrize('metric', [0, 1])
@@ -276,8 +276,13 @@ def test_match_near_ties_vs_golden(cuda, golden_dir, metric):
     else:
         nan = np.isnan(want)
         assert nan.sum() >= 5
-        assert np.all(dist[nan] == 0.0) and np.all(np.isneginf(key[nan]))
+        assert np.all(np.isnan(dist[nan])) and np.all(np.isneginf(key[nan]))     # NaN like the reference
         assert np.abs(dist[~nan].view(np.int32).astype(np.int64) - want[~nan].view(np.int32)).max() <= 4
+        # option "clamp_nan": same winners, distance 0 in place of the NaN of a similarity rounded above 1
+        gal.set_option('clamp_nan', 1)
+        i3, d3 = gal.match(probes, metric)
+        assert np.array_equal(i3, idx) and np.all(d3[nan] == 0.0) and np.array_equal(d3[~nan], dist[~nan])
+        gal.set_option('clamp_nan', 0)
     # one probe at a time and in ragged groups (other tiles, other block counts): same winners
     for lo, hi in ((0, 1), (1, 34), (34, 48)):
         i2, _ = gal.match(probes[lo:hi], metric)
@@ -307,6 +312,93 @@ def test_match_near_ties_sharded(cuda, golden_dir, metric):
         odist = torch.empty(B, dtype=torch.float32, device='cuda')
         N.check(N.lib.dif_match_merge_packed(N.ptr(packed), R, B, N.ptr(oi), N.ptr(odist), N.stream_ptr()))
         assert np.array_equal(oi.cpu().numpy(), g['idx%d' % metric]), R
+
+
+def _degenerate_cases():
+    return [c[0] for c in gi.match_degenerate_cases()]
+
+
+@pytest.mark.parametrize('name', _degenerate_cases())
+def test_match_degenerate_vs_golden(cuda, golden_dir, name):
+    """zero-norm / tiny / huge / non-finite gallery rows and probes, rows anti-parallel
+    to a probe, an all-zero gallery.  evaluation/utility.py:58-62 guards none of it, so the reference's
+    answer is IEEE arithmetic + np.argmin's first-NaN rule; the fixture holds what the reference returned.
+    Index bit-identical; distance NaN exactly where the reference's is NaN, bit-identical for metric 0,
+    within 4 ulp (arccos) for metric 1.  Also sharded 3 ways through the packed merge."""
+    from deep_insight_face import oneshot, _native as N
+    from deep_insight_face.parallel import shard_bounds
+    g = np.load(os.path.join(golden_dir, 'match_degenerate.npz'))
+    probes, gallery = [(p, gl) for n, p, gl in gi.match_degenerate_cases() if n == name][0]
+    assert np.array_equal(g[name + '_sha'], gi.digest(probes, gallery))
+    B = probes.shape[0]
+    gal = oneshot.Gallery(gallery)
+    p_t = torch.from_numpy(probes).cuda()
+    for metric in (0, 1):
+        want_i, want_d = g['%s_idx%d' % (name, metric)], g['%s_dmin%d' % (name, metric)]
+        idx, dist, key = gal.match(probes, metric, return_key=True)
+        assert np.array_equal(idx, want_i), (metric, np.nonzero(idx != want_i)[0], idx, want_i)
+        nan = np.isnan(want_d)
+        assert np.array_equal(np.isnan(dist), nan), metric
+        assert np.all(np.isneginf(key[nan]))
+        if metric == 0:
+            assert np.array_equal(dist[~nan].view(np.uint32), want_d[~nan].view(np.uint32))
+        elif (~nan).any():
+            assert np.abs(dist[~nan].view(np.int32).astype(np.int64) - want_d[~nan].view(np.int32)).max() <= 4
+        # ragged groups of probes (other tile shapes)
+        for lo, hi in ((0, 1), (1, 12), (12, B)):
+            i2, _ = gal.match(probes[lo:hi], metric)
+            assert np.array_equal(i2, want_i[lo:hi]), (metric, lo, hi)
+        R = 3
+        packed = torch.empty((R, 4 * B), dtype=torch.float32, device='cuda')
+        for r in range(R):
+            lo, hi = shard_bounds(gallery.shape[0], R, r)
+            sh = oneshot.Gallery(gallery[lo:hi], index_base=lo)
+            rec = packed[r]
+            sh.match_into(p_t, metric, rec[2 * B:].view(torch.int64), rec[B:2 * B], rec[:B])
+            torch.cuda.synchronize()
+            sh.close()
+        oi = torch.empty(B, dtype=torch.int64, device='cuda')
+        odist = torch.empty(B, dtype=torch.float32, device='cuda')
+        N.check(N.lib.dif_match_merge_packed(N.ptr(packed), R, B, N.ptr(oi), N.ptr(odist), N.stream_ptr()))
+        assert np.array_equal(oi.cpu().numpy(), want_i), metric
+        assert np.array_equal(np.isnan(odist.cpu().numpy()), nan)
+    gal.close()
+
+
+def test_match_zero_probes_take_no_exact_search(cuda):
+    """padded (all-zero) probe rows under the cosine metric used to overflow every block's
+    candidate list and cost a whole-gallery exact scan each.  They are now answered directly (row 0, NaN --
+    what np.argmin over an all-NaN row returns), and a gallery of zero rows (an unfilled shard) is answered
+    from its first row: neither may take measurably longer than an ordinary batch."""
+    import time
+    from deep_insight_face import oneshot
+    G, B = 200_000, 256
+    gt = torch.nn.functional.normalize(torch.randn((G, 512), device='cuda', generator=torch.Generator('cuda').manual_seed(3)), dim=1)
+    gal = oneshot.Gallery(gt)
+    good = torch.nn.functional.normalize(gt[:B] + 0.01 * torch.randn((B, 512), device='cuda'), dim=1)
+    zeros = torch.zeros((B, 512), device='cuda')
+
+    def timed(p, g_):
+        g_.match(p, 1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = g_.match(p, 1)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, out
+
+    t_good, (i_good, _) = timed(good, gal)
+    t_zero, (i_zero, d_zero) = timed(zeros, gal)
+    assert torch.equal(i_good.cpu(), torch.arange(B))
+    assert torch.all(i_zero == 0) and torch.all(torch.isnan(d_zero))
+    assert t_zero < 5 * t_good + 0.02, (t_zero, t_good)
+    empty_shard = oneshot.Gallery(torch.zeros((G, 512), device='cuda'), index_base=1000)
+    t_es, (i_es, d_es) = timed(good, empty_shard)
+    assert torch.all(i_es == 1000) and torch.all(torch.isnan(d_es))
+    assert t_es < 5 * t_good + 0.02, (t_es, t_good)
+    i0, d0 = empty_shard.match(good, 0)          # metric 0: zero rows are ordinary rows, all tied -> the first
+    assert torch.all(i0 == 1000) and torch.allclose(d0, torch.ones(B, device='cuda'), atol=1e-5)
+    gal.close()
+    empty_shard.close()
 
 
 def test_match_exact_search_on_overflow(cuda):

@@ -143,3 +143,27 @@ def test_numpy_summation_order_restated():
     for r in range(20):
         assert od.np_pairwise_sum(q[0] * gal[r]) == dot[r]
         assert np.sqrt(od.np_pairwise_sum(gal[r] * gal[r])) == nrm[r]
+
+
+def test_degenerate_fixture(golden_dir):
+    """Zero-norm / non-finite / tiny / huge rows and probes, anti-parallel rows: the
+    oracle's arg-min and minimal distance equal the reference's on every case, NaN pattern included."""
+    g = load(golden_dir, 'match_degenerate.npz')
+    cases = gi.match_degenerate_cases()
+    assert len(cases) >= 10
+    seen_nan = 0
+    with np.errstate(all='ignore'):
+        for name, probes, gallery in cases:
+            assert gallery.shape[0] >= 4096
+            assert np.array_equal(g[name + '_sha'], gi.digest(probes, gallery)), name
+            for m in (0, 1):
+                idx, best, _ = od.match(probes, gallery, m)
+                assert np.array_equal(idx, g['%s_idx%d' % (name, m)]), (name, m)
+                assert np.array_equal(best, g['%s_dmin%d' % (name, m)], equal_nan=True), (name, m)
+                seen_nan += int(np.isnan(best).sum())
+    assert seen_nan > 100
+    # what the fixture is for: a zero-norm row is np.argmin's answer for every finite probe under metric 1 ...
+    assert set(g['zero_rows_idx1']) == {417} and np.all(np.isnan(g['zero_rows_dmin1']))
+    # ... but an ordinary row under metric 0; anti-parallel rows produce NaN at the far end of the ranking
+    assert not np.isnan(g['zero_rows_dmin0']).any()
+    assert 5 <= np.isnan(g['antiparallel_dmin1']).sum() < len(g['antiparallel_dmin1'])

@@ -115,3 +115,51 @@ def test_two_ranks_whole_step(cuda, tmp_path):
     z1 = np.load(os.path.join(str(tmp_path), 's1.npz'))
     assert np.array_equal(z0['idx'], z0['pos']) and np.array_equal(z1['idx'], z0['pos'])
     assert np.array_equal(z0['d'], z1['d']) and float(z0['d'].max()) < 0.2
+
+
+def test_single_rank_input_forms(cuda):
+    """with world == 1 ShardedGallery.match hands the caller's tensor to dif_match.  A
+    non-contiguous view, another dtype / device or NumPy input must be converted (as Gallery.match does), a
+    wrong width refused; the allocation-free forms refuse what they cannot take as it is; copy=False returns
+    the step buffers the next call overwrites, copy=True (default) does not."""
+    from deep_insight_face import oneshot
+    from deep_insight_face.parallel import ShardedGallery
+    gal = gi.gallery(3000, seed=5)
+    probes, pick = gi.probes_from(gal, 20, seed=6)
+    sg = ShardedGallery(torch.from_numpy(gal).cuda(), 0)
+    assert sg.world == 1
+    want = torch.from_numpy(pick)
+    wide = torch.zeros((20, 1024), device='cuda')
+    wide[:, :512] = torch.from_numpy(probes).cuda()           # e.g. the first half of a flipped-concat embedding
+    for form in (wide[:, :512], torch.from_numpy(probes).cuda().double(), torch.from_numpy(probes).half(),
+                 torch.from_numpy(probes), probes, torch.from_numpy(probes).cuda().t().contiguous().t()):
+        idx, d = sg.match(form, 1)
+        assert torch.equal(idx.cpu(), want), type(form)
+    with pytest.raises(ValueError, match=r'must be \[b, 512\]'):
+        sg.match(wide, 1)
+    with pytest.raises(ValueError):
+        sg.match(torch.zeros(512, device='cuda'), 1)
+    # buffer-reuse contract
+    p_t = torch.from_numpy(probes).cuda()
+    i1, _ = sg.match(p_t, 1)
+    i2, _ = sg.match(p_t.flip(0), 1)
+    assert torch.equal(i1.cpu(), want) and torch.equal(i2.cpu(), want.flip(0))
+    j1, _ = sg.match(p_t, 1, copy=False)
+    j2, _ = sg.match(p_t.flip(0), 1, copy=False)
+    assert j1.data_ptr() == j2.data_ptr() and torch.equal(j1.cpu(), want.flip(0))
+    # Gallery.match_into: no conversion, so everything it cannot read as dense float32 [B, 512] is refused
+    g = oneshot.Gallery(torch.from_numpy(gal).cuda())
+    oi = torch.empty(20, dtype=torch.int64, device='cuda')
+    od_ = torch.empty(20, dtype=torch.float32, device='cuda')
+    g.match_into(p_t, 1, oi, od_)
+    assert torch.equal(oi.cpu(), want)
+    for bad in (wide[:, :512], p_t.double(), p_t.cpu(), probes, p_t[:, :256]):
+        with pytest.raises(ValueError):
+            g.match_into(bad, 1, oi, od_)
+    with pytest.raises(ValueError):
+        g.match_into(p_t, 1, oi[:10], od_)
+    with pytest.raises(ValueError):
+        g.match_into(p_t, 1, oi.int(), od_)
+    with pytest.raises(ValueError):
+        g.match_into(p_t, 1, oi, od_, key=od_.double())
+    g.close()

@@ -223,3 +223,40 @@ def test_triplet_evaluate_object(cuda, tmp_path, capsys):
     with pytest.raises(AssertionError, match='Wrong labels'):
         TripletEvaluate(model, paths, issame, batches=lambda bs: [(x[:16], np.arange(1, 17))])(16, 5, 1)
     model.close()
+
+
+def test_wrapper_resizes_off_size_crops_on_the_device(cuda, model):
+    """a crop that is not at the embedder's input size is resampled by the library's
+    area-coverage kernel (dif_area_resize), which is what the reference's
+    ``cv2.resize(image, size, interpolation=Image.BICUBIC)`` selects (predictions.py:93,154: PIL's
+    BICUBIC constant 3 == cv2.INTER_AREA).  Checked against oracle/imageops.area_resize -- PARITY UNPINNED:
+    cv2 is absent from the image, the oracle restates INTER_AREA from its published definition -- for
+    shrinking (integer and fractional ratios, non-square sources) and enlarging."""
+    import torch
+    from deep_insight_face import predictions
+    from deep_insight_face.predictions import TripletPrediction
+    from oracle import imageops as oi
+    rng = np.random.default_rng(21)
+    p = model.get_weights()
+    tp = TripletPrediction(model, img_size=(112, 112))
+    for shape in ((224, 224), (160, 160), (250, 250), (300, 180), (117, 131), (96, 96), (64, 80)):
+        img = rng.integers(0, 256, shape + (3,), dtype=np.uint8)
+        got = predictions._resize(img, (112, 112))
+        assert torch.is_tensor(got) and got.is_cuda and got.dtype == torch.uint8 and tuple(got.shape) == (112, 112, 3)
+        want = oi.area_resize(img, 112)
+        diff = np.abs(got.cpu().numpy().astype(np.int32) - want.astype(np.int32))
+        assert diff.max() <= 1 and (diff > 0).mean() < 0.01, (shape, diff.max(), (diff > 0).mean())   # float32 vs float64 rounding at .5
+        emb = tp._embedding(img)
+        assert isinstance(emb, np.ndarray) and emb.shape == (1, 128)
+        ref = nets.embed(want[None].astype(np.float32) / np.float32(255), p, 'resnet', 128, 'v2')
+        assert cosine_gap(emb, ref).max() < 2e-4          # a handful of pixels one grey level apart
+    # non-square target (cv2 takes (width, height))
+    img = rng.integers(0, 256, (200, 100, 3), dtype=np.uint8)
+    got = predictions._resize(img, (50, 100))
+    assert tuple(got.shape) == (100, 50, 3)
+    # mixed batch: one crop at size, one not
+    out = tp._embedding_batch([rng.integers(0, 256, (112, 112, 3), dtype=np.uint8),
+                               rng.integers(0, 256, (150, 150, 3), dtype=np.uint8)])
+    assert out.shape == (2, 128)
+    with pytest.raises(ValueError):
+        predictions._resize(rng.random((150, 150, 3)), (112, 112))       # float images are not resized
