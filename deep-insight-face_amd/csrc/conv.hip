@@ -1075,8 +1075,8 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_pipe_kernel(const C
   // right after the next step's operand loads were issued.  Buffer accesses with an out-of-range
   // offset read zero / are dropped, which replaces every lane predicate; a null tensor gets an empty
   // descriptor.
-  const __amdgpu_buffer_rsrc_t res_rsrc = make_rsrc(a.res, (a.res && !(a.dbg & 2)) ? (uint32_t)((int64_t)a.M * a.Cout * 4) : 0u);
-  const __amdgpu_buffer_rsrc_t y_rsrc = make_rsrc(a.y, (a.y && !(a.dbg & 1)) ? (uint32_t)((int64_t)a.M * a.y_ld * 4) : 0u);
+  const __amdgpu_buffer_rsrc_t res_rsrc = make_rsrc(a.res, a.res ? (uint32_t)((int64_t)a.M * a.Cout * 4) : 0u);
+  const __amdgpu_buffer_rsrc_t y_rsrc = make_rsrc(a.y, a.y ? (uint32_t)((int64_t)a.M * a.y_ld * 4) : 0u);
   const __amdgpu_buffer_rsrc_t y2_rsrc = make_rsrc(a.y2, a.y2 ? (uint32_t)((int64_t)a.M * a.y_ld * 4) : 0u);
   // No block-uniform conditions inside the steps either (the compiler would branch on them): "no tile
   // to retire yet" and "column beyond Cout" are folded into row_lim (rows below it are stored), "no
@@ -1520,8 +1520,6 @@ static int launch_conv_pipe(const ConvArgs& a, hipStream_t st) {
   b.fd_ks = make_fastdiv(a.Kpad / BK);
   b.fd_taps = make_fastdiv(a.KH * a.KW);
   b.fd_tiles_n = make_fastdiv((a.Cout + T::BN - 1) / T::BN);
-  static const int dbg = getenv("DIF_PIPE_DBG") ? atoi(getenv("DIF_PIPE_DBG")) : 0;
-  b.dbg = dbg;
   hipLaunchKernelGGL(kern, dim3((unsigned)P), dim3(T::NT), lds, st, b);
   DIF_HIP(hipGetLastError());
   return 0;
@@ -1529,22 +1527,20 @@ static int launch_conv_pipe(const ConvArgs& a, hipStream_t st) {
 
 // conv_bdp_kernel's restrictions (otherwise the launcher keeps conv_igemm_kernel's B-direct form)
 static bool conv_bdp_ok(const ConvArgs& a) {
-  static const bool on = !(getenv("DIF_NO_BDP") && atoi(getenv("DIF_NO_BDP")));
   // 64-channel layers (18 K-steps per tile) measured 2 % faster one tile per block than on the persistent grid
-  static const int min_ks = getenv("DIF_BDP_MIN_KS") ? atoi(getenv("DIF_BDP_MIN_KS")) : 32;
-  if (!on || a.bdp_mode == 1 || !a.w_frag || a.y_sub) return false;
+  constexpr int min_ks = 32;
+  if (a.bdp_mode == 1 || !a.w_frag || a.y_sub) return false;
   if (a.bdp_mode != 2 && a.Kpad / BK < min_ks) return false;
   if (!(a.y_H == a.Ho && a.y_W == a.Wo && a.y_oy == 0 && a.y_ox == 0 && a.y_ld == a.Cout && a.y_coff == 0)) return false;
   if (a.res && (a.res_stride != 1 || a.res_H != a.Ho || a.res_W != a.Wo)) return false;
   if (a.act == ACT_RELU6 || a.act2 == ACT_RELU6) return false;
   if ((int64_t)a.M * a.Cout * 4 >= 0xFFFFFFF0LL) return false;
-  // more than one tile per resident block (DIF_BDP_MIN_TILES, default 1.5), or there is no next tile to retire the previous one under (ResNet50V2's 3x3
+  // at least 1.5 tiles per resident block, or there is no next tile to retire the previous one under (ResNet50V2's 3x3
   // layers on half-chip lane grids: 0.8-1.5 tiles per block, 1 % slower here than on conv_igemm_kernel)
   const int64_t tiles = ((a.M + 63) / 64) * (int64_t)((a.Cout + 63) / 64);
   int64_t slots = 4 * (int64_t)num_cus();
   if (slots > a.sk_max_blocks) slots = a.sk_max_blocks;
-  static const double min_tiles = getenv("DIF_BDP_MIN_TILES") ? atof(getenv("DIF_BDP_MIN_TILES")) : 1.5;
-  return a.bdp_mode == 2 || (double)tiles >= min_tiles * (double)slots;
+  return a.bdp_mode == 2 || 2 * tiles >= 3 * slots;
 }
 
 template <class T, int AMP>
@@ -1585,8 +1581,7 @@ static int launch_conv_bdp(const ConvArgs& a, hipStream_t st) {
 // returns 0 (no), PATCH_EMAX_S or PATCH_EMAX_L: the smallest patch size that covers every tile of the layer
 static int patch_applies(const ConvArgs& a) {
   constexpr int BM = 64;
-  static const bool on = !(getenv("DIF_NO_PATCH") && atoi(getenv("DIF_NO_PATCH")));
-  if (!on || a.pre_scale || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad_t != 1 || a.pad_l != 1) return 0;
+  if ((a.off & CONV_OFF_PATCH) || a.pre_scale || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad_t != 1 || a.pad_l != 1) return 0;
   if (a.Cin % BK != 0 || a.k_order != 1 || a.Ho != a.H || a.Wo != a.W) return 0;
   const int HW = a.H * a.W, WP = a.W + 2;
   const int row_wraps = (BM - 2) / a.W + 1, img_wraps = a.N > 1 ? (BM - 2) / HW + 1 : 0;
@@ -1597,15 +1592,16 @@ static int patch_applies(const ConvArgs& a) {
 // the 8x8-tile form of the patch path (AM = 6): the same layers on maps whose sides are multiples of 8, where the
 // linear patch would not fit (IResNet's 112x112 and 56x56 layers, VGG16's, the detector's 208 / 104 stages)
 static bool patch2d_applies(const ConvArgs& a) {
-  static const bool on = !(getenv("DIF_NO_PATCH2D") && atoi(getenv("DIF_NO_PATCH2D")));
-  if (!on || a.pre_scale || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad_t != 1 || a.pad_l != 1) return false;
+  if ((a.off & CONV_OFF_PATCH2D) || a.pre_scale || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad_t != 1 || a.pad_l != 1) return false;
   if (a.Cin % BK != 0 || a.k_order != 1 || a.Ho != a.H || a.Wo != a.W) return false;
   if ((int64_t)a.H * a.W * a.Cin * 4 >= 0x7fffffffLL) return false;      // one image per buffer descriptor
   return a.H % 8 == 0 && a.W % 8 == 0 && patch_applies(a) == 0;
 }
 
+constexpr int SK_MIN_KS = 32;   // K-steps per tile from which few-tile layers take the stream-K grid (measured threshold)
+
 static bool pipe_applies(const ConvArgs& a, int64_t tiles, int KS, int64_t slots) {
-  static const int sk_min_ks = getenv("DIF_SK_MIN_KS") ? atoi(getenv("DIF_SK_MIN_KS")) : 32;
+  constexpr int sk_min_ks = SK_MIN_KS;
   if (!a.use_pipe) return false;                                      // dif_net_set_option("pipe", 0)
   if (a.y_sub) return false;                                          // its stores know one output geometry
   if (slots < 8) return false;                                        // the kernel deals tiles out per XCD (8 of them)
@@ -1621,14 +1617,11 @@ static bool pipe_applies(const ConvArgs& a, int64_t tiles, int KS, int64_t slots
 
 template <class T>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
-  // LDS-DMA operand staging is +1..5 % on the plain GEMM microbenchmark but -1.2 % inside this
-  // kernel (interleaved A/B, both networks), so register staging stays the default.
-  static const bool use_dma = getenv("DIF_USE_DMA") && atoi(getenv("DIF_USE_DMA"));
-  // 1x1 / no padding / whole 32-channel K-steps: the pointwise loader (default tile only; the
-  // other tile shapes are experiment knobs and keep the general gather)
-  static const bool use_pw = !(getenv("DIF_NO_PW") && atoi(getenv("DIF_NO_PW")));
+  // (LDS-DMA operand staging was +1..5 % on the plain GEMM microbenchmark but -1.2 % inside this kernel -- interleaved
+  // A/B, both networks -- so operands are staged through registers.)
+  // 1x1 / no padding / whole 32-channel K-steps: the pointwise loader
   constexpr bool kDefaultTile = (T::BM == 64 && T::BN == 64);
-  const bool pw = use_pw && a.KH == 1 && a.KW == 1 && a.pad_t == 0 && a.pad_l == 0 && a.Cin % BK == 0;
+  const bool pw = a.KH == 1 && a.KW == 1 && a.pad_t == 0 && a.pad_l == 0 && a.Cin % BK == 0;
   // (a compile-time specialisation of the 3x3 gather, KMODE 2, was measured 5 % SLOWER than the
   // run-time-selected path on IResNet-100 -- hipcc schedules the loop differently -- so the
   // multi-tap layers stay on the general loader)
@@ -1636,22 +1629,20 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
     const int64_t tiles = ((a.M + T::BM - 1) / T::BM) * (int64_t)((a.Cout + T::BN - 1) / T::BN);
     int64_t slots = 4 * (int64_t)num_cus();
     if (slots > a.sk_max_blocks) slots = a.sk_max_blocks;
-    // DIF_PATCH2D_FIRST=0: the pipelined kernel keeps the short-K 3x3 layers (64 input channels) it took before
-    static const bool p2d_first = !(getenv("DIF_PATCH2D_FIRST") && !atoi(getenv("DIF_PATCH2D_FIRST")));
-    static const bool use_bd = !(getenv("DIF_NO_BD") && atoi(getenv("DIF_NO_BD")));
-    const bool bd = use_bd && a.w_frag != nullptr;
-    if (!use_dma && p2d_first && patch2d_applies(a)) {
+    // (the 8x8-tile patch form ahead of the pipelined kernel, which took the short-K 3x3 layers -- 64 input channels -- before)
+    const bool bd = !(a.off & CONV_OFF_BD) && a.w_frag != nullptr;
+    if (patch2d_applies(a)) {
       if (bd && conv_bdp_ok(a)) return launch_conv_bdp<T, 6>(a, st);
       return bd ? launch_conv_pre<T, false, false, 16>(a, st) : launch_conv_pre<T, false, false, 6>(a, st);
     }
     // the deferred-epilogue patch kernel before the pipelined (gather) one: with very many tiles (batch 512 on one lane)
     // the 128-channel 28x28 layers qualify for both
-    if (!use_dma && bd && !pw && conv_bdp_ok(a)) {
+    if (bd && !pw && conv_bdp_ok(a)) {
       const int emax = patch_applies(a);
       if (emax == PATCH_EMAX_S) return launch_conv_bdp<T, 3>(a, st);
       if (emax == PATCH_EMAX_L) return launch_conv_bdp<T, 5>(a, st);
     }
-    if (!use_dma && a.Cin % 4 == 0 && pipe_applies(a, tiles, a.Kpad / BK, slots)) {
+    if (a.Cin % 4 == 0 && pipe_applies(a, tiles, a.Kpad / BK, slots)) {
       // pointwise layers retire the previous tile four chunks per K-step, i.e. within the first two
       // steps (measured best for every K: 2 steps +16 %, 8 steps +5 % over one chunk per step); the
       // multi-tap layers (18 steps) one chunk per step
@@ -1663,9 +1654,8 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
   if (pw && a.pre_scale) return launch_conv_pre<T, true, false, 1>(a, st);
   if (pw) return launch_conv_pre<T, false, false, 1>(a, st);
   if constexpr (kDefaultTile) {
-    if (!use_dma) {
-      static const bool use_bd2 = !(getenv("DIF_NO_BD") && atoi(getenv("DIF_NO_BD")));
-      const bool bd2 = use_bd2 && a.w_frag != nullptr;
+    {
+      const bool bd2 = !(a.off & CONV_OFF_BD) && a.w_frag != nullptr;
       const int emax = patch_applies(a);
       if (bd2 && conv_bdp_ok(a)) {
         if (emax == PATCH_EMAX_S) return launch_conv_bdp<T, 3>(a, st);
@@ -1678,7 +1668,6 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
     }
   }
   if (a.pre_scale) return launch_conv_pre<T, true, false, 0>(a, st);
-  if (use_dma) return launch_conv_pre<T, false, true, 0>(a, st);
   return launch_conv_pre<T, false, false, 0>(a, st);
 }
 
@@ -1705,8 +1694,7 @@ static int launch_conv_pre(const ConvArgs& a, hipStream_t st) {
   // dispatcher balances them and no tile is ever split.  Few long tiles: stream-K, one equal
   // K-step range per resident block.
   int64_t P;
-  static const int sk_min_ks = getenv("DIF_SK_MIN_KS") ? atoi(getenv("DIF_SK_MIN_KS")) : 32;
-  if (tiles >= 8 * slots || KS < sk_min_ks) {
+  if (tiles >= 8 * slots || KS < SK_MIN_KS) {
     P = tiles;
   } else {
     P = slots;
@@ -1714,11 +1702,7 @@ static int launch_conv_pre(const ConvArgs& a, hipStream_t st) {
   }
   if (P < 1) P = 1;
   ConvArgs b = a;
-  {
-    // slot-weighted stream-K shares: only when the grid is exactly four blocks on each of 256 CUs
-    static const int skew_q16 = (int)((getenv("DIF_SK_SKEW") ? atof(getenv("DIF_SK_SKEW")) : 0.0) * 65536.0);
-    b.sk_skew_q16 = (P == 1024 && P != tiles && num_cus() == 256) ? skew_q16 : 0;
-  }
+  b.sk_skew_q16 = 0;   // slot-weighted stream-K shares (sk_begin) measured no gain: equal shares
   b.fd_howo = make_fastdiv(a.Ho * a.Wo);
   b.fd_wo = make_fastdiv(a.Wo);
   b.fd_cin = make_fastdiv(a.Cin);
@@ -1739,10 +1723,9 @@ static int launch_conv_pre(const ConvArgs& a, hipStream_t st) {
 // Split-bf16 pays where a block gets a long run of K-steps: its tiles are four times the f32 kernel's and it
 // has no pipelined epilogue, so layers with a short K loop or few tiles stay on the f32 kernels even in
 // bf16x3 mode (measured: ResNet50V2's pointwise layers and IResNet's 1x1 downsample / fc lose, every 3x3 layer
-// from 128 channels up gains 1.3-1.5x).  DIF_BF3_MIN_KS / DIF_BF3_MIN_RUN move the thresholds.
+// from 128 channels up gains 1.3-1.5x).
 static bool bf3_pays(const ConvArgs& a) {
-  static const int min_ks = getenv("DIF_BF3_MIN_KS") ? atoi(getenv("DIF_BF3_MIN_KS")) : 9;
-  static const int min_run = getenv("DIF_BF3_MIN_RUN") ? atoi(getenv("DIF_BF3_MIN_RUN")) : 24;
+  constexpr int min_ks = 9, min_run = 24;
   const int KS = a.Kpad / BK;
   const int bm = a.Cout <= 64 ? 256 : 128, bn = a.Cout <= 64 ? 64 : 128;
   const int64_t tiles = ((a.M + bm - 1) / bm) * (int64_t)((a.Cout + bn - 1) / bn);

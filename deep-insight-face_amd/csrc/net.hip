@@ -260,8 +260,7 @@ int Net::build_heads(int feat) {
                  nullptr);
     // triplet.py:129-130  DepthwiseConv2D(kernel = map size) -> BN
     if (fd.H != fd.W) return set_error("GDC head needs a square feature map (got %dx%d)", fd.H, fd.W);
-    static const bool fuse_tail = !(getenv("DIF_NO_TAIL_FUSION") && atoi(getenv("DIF_NO_TAIL_FUSION")));
-    if (fuse_tail && emd <= 1024 && emd % 8 == 0) {
+    if (emd <= 1024 && emd % 8 == 0) {
       // triplet.py:129-138 in ONE launch: depthwise over the whole map + BN -> Conv1x1(emd) ->
       // [Dropout = identity] -> Flatten -> Dense(emd) -> l2_normalize.  0.5 MMAC per image: latency, not MFMA work.
       Op g;
@@ -873,8 +872,54 @@ static void fold(const Net* net, const BNRef& bn, int bias, int C, std::vector<f
   }
 }
 
+// dif_net_set_option (include/dif.h documents the keys a caller may rely on; the rest are development switches that
+// pick between kernel families the parity tests compare)
+int Net::set_option(const char* key, int value) {
+  auto flag = [&](unsigned bit) {
+    conv_off = value ? (conv_off & ~bit) : (conv_off | bit);
+    return 0;
+  };
+  const bool pre = !finalized;
+  if (!strcmp(key, "pipe")) return use_pipe = value != 0, 0;
+  if (!strcmp(key, "bdp")) {
+    if (value < 0 || value > 2) return set_error("dif_net_set_option: 'bdp' takes 0, 1 or 2");
+    return use_bdp = value, 0;
+  }
+  if (!strcmp(key, "stem")) return use_stem = value != 0, 0;
+  if (!strcmp(key, "patch")) return flag(CONV_OFF_PATCH);
+  if (!strcmp(key, "patch2d")) return flag(CONV_OFF_PATCH2D);
+  if (!strcmp(key, "bd")) return flag(CONV_OFF_BD);
+  if (!strcmp(key, "bf16x3")) {
+    if (!pre && compute_bf16x3 != (value != 0))
+      return set_error("dif_net_set_option: 'bf16x3' must be chosen before dif_net_finalize");
+    return compute_bf16x3 = value != 0, 0;
+  }
+  if (!strcmp(key, "ysub") || !strcmp(key, "lane_split")) {
+    if (!pre) return set_error("dif_net_set_option: '%s' must be chosen before dif_net_finalize", key);
+    if (key[0] == 'y') use_ysub = value != 0;
+    else opt_lane_split = value < 0 ? -1 : (value != 0);
+    return 0;
+  }
+  return set_error("dif_net_set_option: unknown option '%s'", key);
+}
+
 int Net::finalize(int mb) {
   if (mb <= 0) return set_error("max_batch must be positive");
+  // development hook: DIF_OPTIONS="key=value,key=value" applies dif_net_set_option keys to every net of the process
+  // (A/B runs of bench.py and the tools without touching their code); unset in production
+  if (const char* env = getenv("DIF_OPTIONS")) {
+    std::string all(env);
+    size_t pos = 0;
+    while (pos < all.size()) {
+      size_t end = all.find(',', pos);
+      if (end == std::string::npos) end = all.size();
+      const std::string kv = all.substr(pos, end - pos);
+      const size_t eq = kv.find('=');
+      if (eq == std::string::npos || eq == 0) return set_error("DIF_OPTIONS: expected key=value, got '%s'", kv.c_str());
+      if (set_option(kv.substr(0, eq).c_str(), atoi(kv.c_str() + eq + 1))) return -1;
+      pos = end + 1;
+    }
+  }
   for (const Param& p : params)
     if (!p.set) return set_error("parameter '%s' was never set", p.name.c_str());
   release_device();
@@ -887,8 +932,7 @@ int Net::finalize(int mb) {
       const int taps = op.KH * op.KW;
       const int K = taps * op.Cin;
       op.Kpad = (K + BK - 1) / BK * BK;
-      static const int want_cbm = getenv("DIF_K_ORDER") ? atoi(getenv("DIF_K_ORDER")) : 1;
-      op.k_order = (want_cbm && taps > 1 && op.Cin % BK == 0 && op.Cin_true == op.Cin) ? 1 : 0;
+      op.k_order = (taps > 1 && op.Cin % BK == 0 && op.Cin_true == op.Cin) ? 1 : 0;
       std::vector<float> packed((size_t)op.Cout * op.Kpad, 0.f);
       const float* w = params[op.w].data.data();   // [taps][Cin_true][Cout] (HWIO) or CHW-flattened dense
       for (int t = 0; t < taps; ++t)
@@ -902,7 +946,6 @@ int Net::finalize(int mb) {
       // 3-channel first layers leave the general kernel.  YOLOv3-face's 3x3 (32 filters) runs as a direct convolution
       // (elementwise.hip): 0.68 ms vs 1.50 ms per 64 frames as an implicit GEMM.  The 64-filter ones (IResNet conv1 3x3,
       // ResNet50V2 conv1_conv 7x7 / 2) run on the MFMA with the true K and the input patch in LDS (stem.hip).
-      static const bool use_stem = !(getenv("DIF_NO_STEM") && atoi(getenv("DIF_NO_STEM")));
       op.d_w_raw = nullptr;
       op.stem_mfma = false;
       const bool stem_shape = use_stem && op.Cin_true == 3 && op.Cin == 4 && op.res < 0 && !op.pre_bn.valid() &&
@@ -995,9 +1038,8 @@ int Net::finalize(int mb) {
   // convolution (IResNet: conv1's activation and the last block of a stage feed the next stage's downsample shortcut,
   // while the batch-normalised second output feeds its 3x3) writes that output subsampled -- a quarter of the bytes;
   // the stem's 822 MB output at batch 256 was the layer's bound -- and the reader runs at stride 1 on the dense quarter.
-  static const bool sub_on = !(getenv("DIF_NO_YSUB") && atoi(getenv("DIF_NO_YSUB")));
   for (Op& P : ops) {
-    if (!sub_on || P.kind != OP_CONV || P.y < 0 || P.y2 < 0 || P.y_sub || is_output(P.y) || tensors[P.y].parent >= 0 ||
+    if (!use_ysub || P.kind != OP_CONV || P.y < 0 || P.y2 < 0 || P.y_sub || is_output(P.y) || tensors[P.y].parent >= 0 ||
         tensors[P.y2].parent >= 0 || P.Cout % 4 != 0)
       continue;
     bool viewed = false;
@@ -1062,7 +1104,6 @@ int Net::finalize(int mb) {
   }
   sk_max_blocks = conv_max_blocks();
   if (const char* e = getenv("DIF_SK_SPIN_LIMIT")) sk_spin_limit = atoi(e);   // test hook (tests/test_embed_gpu.py)
-  if (const char* e = getenv("DIF_PIPE")) use_pipe = atoi(e) != 0;              // read once here, never per launch
   // Lanes: the batch is cut into nl parts that run the launch list on nl streams.
   //  * long launches (IResNet-100 at batch 256: 12 GFLOP per launch per lane): two lanes, each launch sized for the
   //    whole chip -- one lane's tail hides under the other lane's head (+4 %);
@@ -1074,8 +1115,8 @@ int Net::finalize(int mb) {
   for (const Op& op : ops) n_conv += op.kind == OP_CONV;
   const double per_launch = flops_per_image() * (max_batch / 2) / (n_conv > 0 ? n_conv : 1);
   const bool long_launches = per_launch >= 10e9;
-  int nl = getenv("DIF_STREAMS") ? atoi(getenv("DIF_STREAMS")) : 2;
-  lane_split = (getenv("DIF_SK_LANE_SPLIT") ? atoi(getenv("DIF_SK_LANE_SPLIT")) : (long_launches ? 0 : 1)) != 0;
+  int nl = getenv("DIF_STREAMS") ? atoi(getenv("DIF_STREAMS")) : 2;      // tests force the single-lane executor with it
+  lane_split = (opt_lane_split >= 0 ? opt_lane_split : (long_launches ? 0 : 1)) != 0;
   if (nl < 1) nl = 1;
   if (nl > 8) nl = 8;
   if (max_batch < 64 * nl || !extra_outputs.empty()) nl = 1;
@@ -1229,6 +1270,7 @@ int Net::run_op(const Op& op, Lane& L, const void* xin, int n, int layout, int d
       a.sk_epoch = ++L.sk_epoch;
       a.sk_spin_limit = sk_spin_limit;
       a.use_pipe = use_pipe;
+      a.off = conv_off;
       a.bdp_mode = use_bdp == 2 ? 2 : ((use_bdp == 0 || lane_split) ? 1 : 0);
       a.trace = trace_buf ? trace_buf + trace_off[&op - ops.data()] * 8 : nullptr;
       if (op.d_w_raw && op.stem_mfma && use_stem) {

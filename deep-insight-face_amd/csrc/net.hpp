@@ -134,6 +134,10 @@ struct Net {
   int use_pipe = 1;                 // option "pipe": 0 keeps every convolution on conv_igemm_kernel
   int use_bdp = 1;                  // option "bdp": 0 never conv_bdp_kernel, 1 where it pays, 2 wherever it can run
   int use_stem = 1;                 // option "stem": 0 runs 3-channel first layers on conv_igemm_kernel too
+  int use_ysub = 1;                 // option "ysub" (before finalize): 0 keeps outputs read only at stride 2 dense
+  int opt_lane_split = -1;          // option "lane_split" (before finalize): -1 by work per launch, 0 / 1 forced
+  unsigned conv_off = 0;            // options "patch", "patch2d", "bd" = 0: CONV_OFF_* bits handed to every convolution
+  int set_option(const char* key, int value);   // dif_net_set_option; also applied from DIF_OPTIONS="key=value,..." at finalize
 
   ~Net();
   int build();                       // dispatch on arch/head

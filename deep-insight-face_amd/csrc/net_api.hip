@@ -99,26 +99,7 @@ int dif_net_embed_clock(dif_net* h, const void* x_dev, int n, int layout, int dt
 
 int dif_net_set_option(dif_net* h, const char* key, int value) {
   if (!h || !key) return set_error("dif_net_set_option: null argument");
-  if (!strcmp(key, "pipe")) {
-    h->net.use_pipe = value != 0;
-    return 0;
-  }
-  if (!strcmp(key, "bdp")) {
-    if (value < 0 || value > 2) return set_error("dif_net_set_option: 'bdp' takes 0, 1 or 2");
-    h->net.use_bdp = value;
-    return 0;
-  }
-  if (!strcmp(key, "stem")) {
-    h->net.use_stem = value != 0;
-    return 0;
-  }
-  if (!strcmp(key, "bf16x3")) {
-    if (h->net.finalized && h->net.compute_bf16x3 != (value != 0))
-      return set_error("dif_net_set_option: 'bf16x3' must be chosen before dif_net_finalize");
-    h->net.compute_bf16x3 = value != 0;
-    return 0;
-  }
-  return set_error("dif_net_set_option: unknown option '%s'", key);
+  return h->net.set_option(key, value);
 }
 
 int dif_net_output_dim(const dif_net* h, int64_t shape[3]) {

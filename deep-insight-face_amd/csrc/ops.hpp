@@ -38,6 +38,8 @@ inline FastDiv make_fastdiv(int d) {
   return f;
 }
 
+enum { CONV_OFF_PATCH = 1, CONV_OFF_PATCH2D = 2, CONV_OFF_BD = 4 };
+
 struct ConvArgs {
   const float* x;       // [N,H,W,Cin] NHWC
   const float* w;       // packed [Cout][Kpad], zero padded; k order per k_order
@@ -88,7 +90,7 @@ struct ConvArgs {
                         // launches are short and the lanes run half-chip grids: measured 1-2 % slower there; Net option
                         // "bdp" = 0), 2 wherever its restrictions allow (Net option "bdp" = 2: the parity tests)
   int use_pipe;         // 0: never take the software-pipelined kernel (Net option "pipe"; tests compare both paths)
-  int dbg;              // development aid: bit 0 drops the pipelined kernel's stores, bit 1 its shortcut loads
+  unsigned off;         // kernel families switched off (Net options "patch", "patch2d", "bd" = 0): CONV_OFF_* bits
   // development aid (tools/ubench/conv_trace.hip), null in the library: 4 x u64 per hardware block =
   // s_memrealtime (100 MHz) at entry / after the first mainloop / at exit, and the HW_ID register
   unsigned long long* trace;
