@@ -33,7 +33,10 @@
 #include <stdlib.h>
 
 #include <atomic>
+#include <mutex>
+#include <set>
 #include <type_traits>
+#include <utility>
 
 namespace dif {
 
@@ -639,6 +642,237 @@ __device__ __forceinline__ void gemm_mainloop_patch_bd(const PA& pa, const ConvA
   __syncthreads();
 }
 
+// ------------------------------------------------------------------------------------------
+// Split-bf16 ("bf16x3") form of the B-direct patch mainloop: the throughput mode's kernel for 3x3 / stride 1 layers.
+//
+// Arithmetic as gemm_core.hpp's gemm_mainloop_bf3 (every f32 operand = hi + mid + lo in bf16, six products per pair on
+// v_mfma_f32_32x32x16_bf16, f32 accumulation, the same product order), data movement as gemm_mainloop_patch_bd:
+//   * A: the tile's pixels + halo lie in LDS once per 32-channel slice, ALREADY SPLIT: an entry is [3 planes][32 bf16]
+//     (+ 16 bytes: 208-byte entries, so the 16 lanes of a ds_read_b128 group touch 16 distinct 16-byte bank groups).
+//     The split costs 22 VALU per four values once per slice (nine K-steps), not once per K-step as in the gather
+//     kernel, and a tap is an address offset;
+//   * B: the weights, split once at finalize and stored in FRAGMENT order (ConvArgs::w3f:
+//     [Cout/32][Kpad/32][s 2][plane 3][lane 64][8 bf16] <- plane(w[32 nt + (lane & 31)][32 ks + 16 s + 8 (lane >> 5) + t])),
+//     go from L2 straight into the MFMA operand registers, one 16-k sub-step ahead; no LDS, no barrier per K-step.
+// Block = 4 waves, each 64 x 64 (2 x 2 fragments: 64 accumulator registers) -> 128 pixels x 128 channels; two blocks
+// per CU = two waves per SIMD with the full 256-register budget (the gather kernel's 128 registers spilled 200-300).
+// Per wave and K-step: 48 MFMAs (1536 matrix-pipe cycles) against 12 ds_read_b128 and 12 coalesced 1 KB loads.
+constexpr int BF3P_EB = 208;          // bytes per patch entry
+constexpr int BF3P_KSTEP_B = 6144;    // bytes of w3f per (32-column tile, K-step)
+constexpr int PATCH_EMAX_B3 = 232;    // entries a 128-pixel linear tile can need on maps up to 28 wide (host-checked bound)
+constexpr int BF3P_PLANES_B = PATCH_EMAX_B3 * BF3P_EB;            // the split patch ...
+constexpr int BF3P_STAGE_B = PATCH_EMAX_B3 * 128;                 // ... and, behind it, the next slice's f32 patch as it arrives
+constexpr int BF3P_LDS_B = BF3P_PLANES_B + BF3P_STAGE_B;
+
+// The f32 patch of one 32-channel slice, fetched global -> LDS by LDS-DMA (buffer_load ... lds: no staging registers --
+// held in registers across the five taps it is in flight the prefetch cost 32 VGPRs, and every scratch reload of a spilled
+// value waits, through the in-order vmcnt, for the B fragments requested before it).  Slot s = (entry s >> 3, 4-channel
+// chunk s & 7) is fetched by thread s % 256 into staging byte 16 s (lane-linear per wave instruction); halo and tail slots
+// get an out-of-range offset and land as zeros.  Source offsets are recomputed per slice (two mul-hi divisions per slot)
+// instead of being kept: eight more registers, or eight scratch reloads in the loop.
+template <class T, int EMAX_>
+struct PatchDma {
+  static constexpr int EMAX = EMAX_;
+  static constexpr int NPC = (EMAX * 8 + T::NT - 1) / T::NT;
+  __amdgpu_buffer_rsrc_t rsrc;
+  int base[T::WM];      // entry of this lane's output pixels, tap (0, 0)
+  int WP, origin, H, W, Cin4, imgs;
+  FastDiv fd_wp, fd_rpi;
+  __device__ __forceinline__ PatchDma(const ConvArgs& a, int m0) {
+    const int lane = threadIdx.x & 63;
+    const int HW = a.H * a.W;
+    WP = a.W + 2;
+    H = a.H;
+    W = a.W;
+    Cin4 = a.Cin * 4;
+    fd_wp = a.fd_wp;
+    fd_rpi = a.fd_rpi;
+    const int RPI = a.H + 1;
+    int n_first, r0;
+    a.fd_howo.divmod(m0, n_first, r0);
+    const int64_t img_elems = (int64_t)HW * a.Cin;
+    const int64_t imgs_left = a.N - n_first;
+    int64_t span = (T::BM + HW - 1) / HW + 1;
+    if (span > imgs_left) span = imgs_left;
+    imgs = (int)span;
+    rsrc = make_rsrc(a.x + n_first * img_elems, (uint32_t)(span * img_elems * 4));
+    int h0, w0;
+    a.fd_wo.divmod(r0, h0, w0);
+    const int p_first = (h0 + 1) * WP + (w0 + 1);
+    origin = p_first - WP - 1;
+#pragma unroll
+    for (int mi = 0; mi < T::WM; ++mi) {
+      int m = m0 + (T::wave_row() * T::WM + mi) * 32 + (lane & 31);
+      if (m >= a.M) m = m0;
+      int n, r, h, w;
+      a.fd_howo.divmod(m, n, r);
+      a.fd_wo.divmod(r, h, w);
+      base[mi] = ((n - n_first) * RPI + h + 1) * WP + (w + 1) - p_first;
+    }
+  }
+  __device__ __forceinline__ void issue(int cblk, char* staging) const {
+    const int wave = threadIdx.x >> 6;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));                          // keeps the offsets from being hoisted out of the K loop (and spilled)
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      const int slot = tid + T::NT * j;
+      const int e = slot >> 3, q = slot & 7;
+      int row, col, img, hp;
+      fd_wp.divmod(origin + e, row, col);
+      fd_rpi.divmod(row, img, hp);
+      const bool ok = e < EMAX && hp >= 1 && col >= 1 && col <= W && img < imgs;
+      const uint32_t off = ok ? (uint32_t)(((img * H + (hp - 1)) * W + (col - 1)) * Cin4 + q * 16 + cblk * 128) : OOB;
+      if ((wave * 64 + T::NT * j) < EMAX * 8)             // wave-uniform: whole instructions beyond the patch are skipped
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(staging + (wave * 64 + T::NT * j) * 16), 16, off, 0, 0, 0);
+    }
+  }
+  // staging (f32, slot-linear) -> the split planes; every thread converts the slots it fetched itself
+  __device__ __forceinline__ void convert(const char* staging, char* planes) const {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));                          // as in issue(): recompute the slot addresses, do not keep them
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      const int slot = tid + T::NT * j;
+      if (slot < EMAX * 8) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(staging + slot * 16);
+        u32x2 hi, mid, lo;
+        bf3_split(v, hi, mid, lo);
+        char* w = planes + (slot >> 3) * BF3P_EB + (slot & 7) * 8;
+        *reinterpret_cast<u32x2*>(w) = hi;
+        *reinterpret_cast<u32x2*>(w + 64) = mid;
+        *reinterpret_cast<u32x2*>(w + 128) = lo;
+      }
+    }
+  }
+};
+
+// LDS-only workgroup barrier: the fences name the local address space, so the compiler waits for this wave's LDS
+// operations (lgkmcnt) but leaves its global loads -- the B fragments requested ahead -- in flight across the barrier
+// (__syncthreads() drains vmcnt as well: the whole prefetch, at every patch swap)
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// K-steps [9 cbeg, 9 cend): whole 32-channel slices (the kernel cuts its stream-K shares at slice boundaries).  One slice =
+// nine taps = 18 sub-steps of 24 MFMAs, written out as straight-line code: the tap is a compile-time constant (an immediate
+// address offset), nothing is carried through a branch, and three rings turn at fixed phase --
+//   B fragments: three sub-step sets, requested TWO sub-steps (one K-step, >= 1536 matrix cycles) ahead: an L2 miss served
+//                by the MALL takes longer than one sub-step under load;
+//   A fragments: two sets, read one sub-step ahead;
+//   the patch:   the next slice's f32 patch arrives by LDS-DMA under taps 4..8 and is split into the planes at the slice
+//                boundary, between two LDS-only barriers (the B ring stays in flight).
+template <class T, class PA>
+__device__ __forceinline__ void gemm_mainloop_patch_bf3(const PA& pa, const ConvArgs& a, int n0, int cbeg, int cend,
+                                                        char* lds, f32x16 (&acc)[T::WM][T::WN]) {
+  constexpr int WM = T::WM, WN = T::WN;
+  static_assert(WM * WN == 4 && T::NT == 256, "split-bf16 patch path: four waves, four accumulator fragments each");
+  const int lane = threadIdx.x & 63, h = lane >> 5;
+  const int KS = a.Kpad / BK;
+  char* staging = lds + BF3P_PLANES_B;
+  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.w3f, a.w3f_bytes);
+  uint32_t boff[WN];
+#pragma unroll
+  for (int n = 0; n < WN; ++n)
+    boff[n] = (uint32_t)((n0 >> 5) + T::wave_col() * WN + n) * (uint32_t)KS * (uint32_t)BF3P_KSTEP_B + (uint32_t)lane * 16u;
+  const int klast = 9 * cend - 1;
+  // sub-step index u = 2 * K-step + half; past the range the last K-step is fetched again (branch-free, never used)
+  auto bload = [&](int u, u32x4 (&b)[WN][3]) {
+    // (no run-time condition around these loads: at a join behind a skipped load group the compiler must assume the
+    // FEWEST younger loads, i.e. wait for vmcnt(0), and the ring's lookahead is gone)
+    int ks = u >> 1;
+    ks = ks < klast ? ks : klast;
+    const uint32_t so = (uint32_t)ks * (uint32_t)BF3P_KSTEP_B + (uint32_t)(u & 1) * 3072u;
+#pragma unroll
+    for (int n = 0; n < WN; ++n)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) b[n][p] = __builtin_amdgcn_raw_buffer_load_b128(wrs, boff[n], so + (uint32_t)p * 1024u, 0);
+  };
+  uint32_t arow[WM];                                        // byte address of (this lane's pixel, tap row kh, kw = 0), per m
+  auto aread = [&](int kw, int s, u32x4 (&f)[WM][3]) {
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        f[m][p] = *reinterpret_cast<const u32x4*>(lds + arow[m] + kw * BF3P_EB + p * 64 + s * 32);
+  };
+  // lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi (small terms first); the four accumulators take turns
+  auto mfma24 = [&](const u32x4 (&fa)[WM][3], const u32x4 (&fb)[WN][3]) {
+    constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int n = 0; n < WN; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[m][QA[q]]),
+                                                              __builtin_bit_cast(bf16x8, fb[n][QB[q]]), acc[m][n], 0, 0, 0);
+  };
+  auto set_row = [&](int kh) {
+#pragma unroll
+    for (int m = 0; m < WM; ++m) arow[m] = (uint32_t)(pa.base[m] + kh * pa.WP) * (uint32_t)BF3P_EB + (uint32_t)h * 16u;
+  };
+
+  u32x4 bq[3][WN][3];
+  u32x4 fa[2][WM][3];
+  pa.issue(cbeg, staging);
+  bload(18 * cbeg, bq[0]);
+  bload(18 * cbeg + 1, bq[1]);
+  if constexpr (WN == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // the patch has landed (the B loads behind it may be in flight)
+  else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  pa.convert(staging, lds);
+  lds_barrier();
+  for (int cb = cbeg; cb < cend; ++cb) {
+    const int u0 = 18 * cb;
+    set_row(0);
+    aread(0, 0, fa[0]);
+    // sub-step I of the slice (compile time): tap I / 2, half I % 2
+    auto substep = [&](auto ic) {
+      constexpr int I = decltype(ic)::value;
+      constexpr int N = I + 1, ntap = N / 2;               // the sub-step whose A fragments are read now
+      if constexpr (N < 18) {
+        if constexpr (N % 6 == 0) set_row(ntap / 3);       // next tap row
+        aread(ntap % 3, N & 1, fa[N & 1]);
+      }
+      bload(u0 + I + 2, bq[(I + 2) % 3]);
+      if constexpr (I == 2 * PATCH_PF_TAP) {
+        if (cb + 1 < cend) pa.issue(cb + 1, staging);      // lands while the remaining taps run
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma24(fa[I & 1], bq[I % 3]);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    substep(std::integral_constant<int, 0>());
+    substep(std::integral_constant<int, 1>());
+    substep(std::integral_constant<int, 2>());
+    substep(std::integral_constant<int, 3>());
+    substep(std::integral_constant<int, 4>());
+    substep(std::integral_constant<int, 5>());
+    substep(std::integral_constant<int, 6>());
+    substep(std::integral_constant<int, 7>());
+    substep(std::integral_constant<int, 8>());
+    substep(std::integral_constant<int, 9>());
+    substep(std::integral_constant<int, 10>());
+    substep(std::integral_constant<int, 11>());
+    substep(std::integral_constant<int, 12>());
+    substep(std::integral_constant<int, 13>());
+    substep(std::integral_constant<int, 14>());
+    substep(std::integral_constant<int, 15>());
+    substep(std::integral_constant<int, 16>());
+    substep(std::integral_constant<int, 17>());
+    if (cb + 1 < cend) {
+      if constexpr (WN == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // this thread's share of the next patch is in LDS
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      lds_barrier();                                       // every wave has read its last fragment of the old patch
+      pa.convert(staging, lds);
+      lds_barrier();
+    }
+  }
+  __syncthreads();
+}
+
 __device__ __forceinline__ float apply_act(float v, int act, float alpha) {
   if (act == ACT_RELU) return fmaxf(v, 0.f);
   if (act == ACT_PRELU) return v >= 0.f ? v : v * alpha;
@@ -801,18 +1035,22 @@ __device__ __forceinline__ int xcd_remap(int b, int P) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }
 
+struct NoLoader {};   // B operand of the B-direct kernels: fetched by the mainloop itself
+
 // AM (A-operand gather mode): 0 general, 1 pointwise (1x1, no padding, Cin % 32 == 0),
 // 2 multi-tap with Cin % 32 == 0 and channel-block-major K
-// BF3: the split-bf16 mainloop (gemm_core.hpp: gemm_mainloop_bf3) on pre-split weights a.w3
+// BF3 (with AM = 13): the split-bf16 patch kernel, gemm_mainloop_patch_bf3 on the fragment-order split weights a.w3f
 template <class T, bool PRE, bool DMA, int AM, bool BF3 = false>
 __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const ConvArgs a) {
   static_assert(!(PRE && DMA), "pre-activation needs register staging");
   static_assert(!(AM != 0 && DMA), "the specialised loaders are register-staged");
-  static_assert(!(BF3 && DMA), "the split-bf16 mainloop stages through registers");
+  static_assert(!BF3 || (AM == 13 && !PRE && !DMA), "split-bf16 exists as the B-direct patch kernel only");
   constexpr int AMP = AM % 10;                              // AM >= 10: the B-direct form of patch path AM - 10
   constexpr bool PATCH = (AMP == 3 || AMP == 5 || AMP == 6), BD = AM >= 10;
   static_assert(!BD || PATCH, "B-direct exists for the patch paths only");
-  static_assert(!PATCH || (!PRE && !DMA && !BF3 && T::BM == 64 && T::BN == 64), "patch path: plain f32, 64x64 tile");
+  constexpr bool B3P = BF3 && PATCH;                         // split-bf16 patch kernel: gemm_mainloop_patch_bf3
+  static_assert(!PATCH || (!PRE && !DMA), "patch path: no pre-activation, register staging");
+  static_assert(!PATCH || (B3P ? (BD && T::BM == 128 && T::BN == 128 && AMP == 3) : (T::BM == 64 && T::BN == 64)), "patch path tiles");
   constexpr int WM = T::WM, WN = T::WN;
   constexpr int SLAB = T::BM * T::BN;    // floats per partial-accumulator slab
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -820,7 +1058,8 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const 
   const int tid = threadIdx.x;
   const int P = gridDim.x;
   const int p = xcd_remap(blockIdx.x, P);
-  const int KS = a.Kpad / BK;
+  // iteration unit of the stream-K split: a K-step; a 32-channel slice (nine K-steps) for the split-bf16 patch kernel
+  const int KS = (BF3 && AM >= 10) ? a.Kpad / (BK * 9) : a.Kpad / BK;
   const int tiles_n = (a.Cout + T::BN - 1) / T::BN;
   const int tiles_m = (a.M + T::BM - 1) / T::BM;
   const int I = tiles_m * tiles_n * KS;                       // < 2^31 (checked by conv_run)
@@ -863,15 +1102,15 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const 
     using ALoadReg = typename std::conditional<AM == 1, ConvPwLoader<T::NA, T::RP, PRE>,
                                                ConvALoader<T::NA, T::RP, PRE, AM == 2 ? 2 : 0>>::type;
     using ALoadGather = typename std::conditional<DMA, ConvADmaLoader<T::NA, T::RP>, ALoadReg>::type;
-    using ALoadLin = typename std::conditional<AMP == 3, PatchA<T, PATCH_EMAX_S>,                 // AM 3 / 5 / 6: halo-resident patch
+    using ALoadLin = typename std::conditional<AMP == 3, typename std::conditional<B3P, PatchDma<T, PATCH_EMAX_B3>, PatchA<T, PATCH_EMAX_S>>::type,   // AM 3 / 5 / 6: halo-resident patch
                                                typename std::conditional<AMP == 5, PatchA<T, PATCH_EMAX_L>, ALoadGather>::type>::type;
     using ALoad = typename std::conditional<AMP == 6, PatchA2D<T>, ALoadLin>::type;
     using BLoadF32 = typename std::conditional<DMA, DmaRowLoader<T::NB, T::RP>, RowLoader<T::NB, T::RP>>::type;
-    using BLoad = typename std::conditional<BF3, Bf3WeightLoader<T>, BLoadF32>::type;
+    using BLoad = typename std::conditional<B3P, NoLoader, BLoadF32>::type;
     ALoad al(a, m0);
     BLoad bl = [&] {
-      if constexpr (BF3)
-        return BLoad(static_cast<const char*>(a.w3) + (int64_t)n0 * KS * BF3_KSTEP_BYTES, (int64_t)a.Cout - n0, KS);
+      if constexpr (B3P)
+        return BLoad();
       else
         return BLoad(a.w + (int64_t)n0 * a.Kpad, (int64_t)a.Cout - n0, a.Kpad);
     }();
@@ -880,10 +1119,8 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const 
     const bool whole = !DMA && !PATCH && kb == 0 && ke == KS;
     EpiRes<T> er;
     auto run = [&](int k0, int k1, bool prefetch_res) {
-      if constexpr (BF3)
-        gemm_mainloop_bf3<T>(al, bl, k0, k1, reinterpret_cast<char*>(smem), acc, [&] {
-          if (prefetch_res && a.res) er.load(a, m0, n0);
-        });
+      if constexpr (B3P)
+        gemm_mainloop_patch_bf3<T>(al, a, n0, k0, k1, reinterpret_cast<char*>(smem), acc);
       else if constexpr (BD)
         gemm_mainloop_patch_bd<T>(al, a, n0, k0, k1, smem, acc, [&] {
           if (prefetch_res && a.res) er.load(a, m0, n0);
@@ -997,7 +1234,8 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const 
         kdone = q_ke;
       }
       if (a.trace) tC = __builtin_amdgcn_s_memrealtime();
-      conv_epilogue<T, !PATCH, AMP == 6, !BF3>(a, acc, m0, n0, smem, er, whole);
+      // (the split-bf16 kernel's operand rings are dead by now: it has the registers to fetch the shortcut tile at once)
+      conv_epilogue<T, !PATCH || B3P, AMP == 6, !BF3>(a, acc, m0, n0, smem, er, whole);
     }
     if (a.trace) {
       const unsigned long long tD = __builtin_amdgcn_s_memrealtime();
@@ -1483,14 +1721,16 @@ static int num_cus() {
   return c;
 }
 
-template <class K>
-static int allow_dynamic_lds(K kern, int bytes) {
-  static std::atomic<unsigned char> done[kMaxDevices];   // one array per kernel instantiation
+// hipFuncAttributeMaxDynamicSharedMemorySize, once per (device, kernel).  Keyed on the kernel's ADDRESS: every
+// convolution kernel has the same function type, so a per-type flag would be shared by all of them.
+static int allow_dynamic_lds(const void* kern, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<int, const void*>> done;
   const int dev = cur_device();
-  if (!done[dev].load(std::memory_order_acquire)) {
-    DIF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    done[dev].store(1, std::memory_order_release);
-  }
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.count({dev, kern})) return 0;
+  DIF_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  done.insert({dev, kern});
   return 0;
 }
 
@@ -1507,7 +1747,7 @@ template <class T, bool PRE, int AM, int CPS = 1>
 static int launch_conv_pipe(const ConvArgs& a, hipStream_t st) {
   auto kern = conv_pipe_kernel<T, PRE, AM, CPS>;
   constexpr int lds = T::LDS_BYTES;
-  if (allow_dynamic_lds(kern, lds)) return -1;
+  if (allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return -1;
   const int64_t tiles = ((a.M + T::BM - 1) / T::BM) * (int64_t)((a.Cout + T::BN - 1) / T::BN);
   int64_t slots = 4 * (int64_t)num_cus();
   if (slots > a.sk_max_blocks) slots = a.sk_max_blocks;
@@ -1548,7 +1788,7 @@ static int launch_conv_bdp(const ConvArgs& a, hipStream_t st) {
   auto kern = conv_bdp_kernel<T, AMP>;
   constexpr int emax = AMP == 3 ? PATCH_EMAX_S : (AMP == 5 ? PATCH_EMAX_L : 100);
   constexpr int lds_bytes = emax * 128 + 16 * T::NT * 4 + 16;      // patch + retiring accumulators + time-out word
-  if (allow_dynamic_lds(kern, lds_bytes)) return -1;
+  if (allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds_bytes)) return -1;
   const int64_t tiles = ((a.M + T::BM - 1) / T::BM) * (int64_t)((a.Cout + T::BN - 1) / T::BN);
   const int KS = a.Kpad / BK;
   const int64_t I = tiles * KS;
@@ -1579,14 +1819,26 @@ static int launch_conv_bdp(const ConvArgs& a, hipStream_t st) {
 // 64-pixel tile's halo patch bounded by PATCH_EMAX entries (row wraps add 2 entries each, an image boundary adds
 // one padded row).  IResNet's 28x28, 14x14 and 7x7 stages qualify; 56x56 and up keep the per-K-step gather.
 // returns 0 (no), PATCH_EMAX_S or PATCH_EMAX_L: the smallest patch size that covers every tile of the layer
-static int patch_applies(const ConvArgs& a) {
-  constexpr int BM = 64;
-  if ((a.off & CONV_OFF_PATCH) || a.pre_scale || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad_t != 1 || a.pad_l != 1) return 0;
-  if (a.Cin % BK != 0 || a.k_order != 1 || a.Ho != a.H || a.Wo != a.W) return 0;
+static bool patch_shape(const ConvArgs& a) {
+  if ((a.off & CONV_OFF_PATCH) || a.pre_scale || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad_t != 1 || a.pad_l != 1) return false;
+  return a.Cin % BK == 0 && a.k_order == 1 && a.Ho == a.H && a.Wo == a.W;
+}
+// entries the halo patch of a BM-pixel linear tile can need
+static int patch_entry_bound(const ConvArgs& a, int BM) {
   const int HW = a.H * a.W, WP = a.W + 2;
   const int row_wraps = (BM - 2) / a.W + 1, img_wraps = a.N > 1 ? (BM - 2) / HW + 1 : 0;
-  const int e_bound = (BM - 1) + 2 * row_wraps + WP * img_wraps + 2 * WP + 4;
+  return (BM - 1) + 2 * row_wraps + WP * img_wraps + 2 * WP + 4;
+}
+static int patch_applies(const ConvArgs& a) {
+  if (!patch_shape(a)) return 0;
+  const int e_bound = patch_entry_bound(a, 64);
   return e_bound <= PATCH_EMAX_S ? PATCH_EMAX_S : (e_bound <= PATCH_EMAX_L ? PATCH_EMAX_L : 0);
+}
+// the split-bf16 patch kernel (128 x 128 tile): layers with at least 128 output channels on maps up to 28 wide
+static bool bf3p_applies(const ConvArgs& a) {
+  if (!a.w3f || !patch_shape(a) || a.y_sub || a.Cout < 128) return false;
+  if (!(a.y_H == a.Ho && a.y_W == a.Wo && a.y_oy == 0 && a.y_ox == 0)) return false;
+  return patch_entry_bound(a, 128) <= PATCH_EMAX_B3;
 }
 
 // the 8x8-tile form of the patch path (AM = 6): the same layers on maps whose sides are multiples of 8, where the
@@ -1679,11 +1931,12 @@ static int launch_conv_pre(const ConvArgs& a, hipStream_t st) {
   constexpr int epi_bytes = T::BM * (T::BN + 4) * 4;       // the epilogue's staging tile
   // B-direct: the patch alone (or the epilogue's staging tile if that is larger)
   constexpr int bd_bytes = emax * 128 > epi_bytes ? emax * 128 : epi_bytes;
-  constexpr int lds_bytes = BF3 ? Bf3<T>::LDS_BYTES
+  constexpr int b3p_bytes = BF3P_LDS_B > epi_bytes ? BF3P_LDS_B : epi_bytes;
+  constexpr int lds_bytes = BF3 ? b3p_bytes
                                 : (AM >= 10 ? bd_bytes : ((AMP == 3 || AMP == 5 || AMP == 6) ? patch_lds_bytes(emax) : T::LDS_BYTES));
-  if (allow_dynamic_lds(kern, lds_bytes)) return -1;
+  if (allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds_bytes)) return -1;
   const int64_t tiles = ((a.M + T::BM - 1) / T::BM) * (int64_t)((a.Cout + T::BN - 1) / T::BN);
-  const int KS = a.Kpad / BK;
+  const int KS = (BF3 && AM >= 10) ? a.Kpad / (BK * 9) : a.Kpad / BK;     // stream-K units (the kernel's `KS`)
   const int64_t I = tiles * KS;
   if (I >= 0x7fffffffLL) return set_error("conv: iteration space too large");
   // Resident blocks for this tile shape (LDS-limited: 2 per CU, 4 for the 64x64 tile).
@@ -1694,7 +1947,7 @@ static int launch_conv_pre(const ConvArgs& a, hipStream_t st) {
   // dispatcher balances them and no tile is ever split.  Few long tiles: stream-K, one equal
   // K-step range per resident block.
   int64_t P;
-  if (tiles >= 8 * slots || KS < SK_MIN_KS) {
+  if (tiles >= 8 * slots || a.Kpad / BK < SK_MIN_KS) {
     P = tiles;
   } else {
     P = slots;
@@ -1718,18 +1971,6 @@ static int launch_conv_pre(const ConvArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3((unsigned)P), dim3(T::NT), lds_bytes, st, b);
   DIF_HIP(hipGetLastError());
   return 0;
-}
-
-// Split-bf16 pays where a block gets a long run of K-steps: its tiles are four times the f32 kernel's and it
-// has no pipelined epilogue, so layers with a short K loop or few tiles stay on the f32 kernels even in
-// bf16x3 mode (measured: ResNet50V2's pointwise layers and IResNet's 1x1 downsample / fc lose, every 3x3 layer
-// from 128 channels up gains 1.3-1.5x).
-static bool bf3_pays(const ConvArgs& a) {
-  constexpr int min_ks = 9, min_run = 24;
-  const int KS = a.Kpad / BK;
-  const int bm = a.Cout <= 64 ? 256 : 128, bn = a.Cout <= 64 ? 64 : 128;
-  const int64_t tiles = ((a.M + bm - 1) / bm) * (int64_t)((a.Cout + bn - 1) / bn);
-  return KS >= min_ks && tiles * KS >= (int64_t)min_run * 2 * num_cus();
 }
 
 // The f32 path ships ONE tile shape: 64x64 (four blocks per CU).  Measured per layer over both networks against
@@ -1757,18 +1998,8 @@ int conv_run(const ConvArgs& a, hipStream_t st) {
     if (span * a.H * a.W * a.Cin * 4 >= 0x7fffffffLL)
       return set_error("conv: a 256-pixel tile spans more than 2 GiB of input (%dx%dx%d)", a.H, a.W, a.Cin);
   }
-  if (a.w3 && bf3_pays(a) && !a.y_sub) {
-    // split-bf16 mode (8 waves, 128x128; 256x64 for narrow layers): stream-K / one tile per block as for f32
-    const bool pw = a.KH == 1 && a.KW == 1 && a.pad_t == 0 && a.pad_l == 0 && a.Cin % BK == 0;
-    if (a.Cout <= 64) {
-      using T = Tile<2, 1, 4, 2>;
-      if (pw) return a.pre_scale ? launch_conv_pre<T, true, false, 1, true>(a, st) : launch_conv_pre<T, false, false, 1, true>(a, st);
-      return a.pre_scale ? launch_conv_pre<T, true, false, 0, true>(a, st) : launch_conv_pre<T, false, false, 0, true>(a, st);
-    }
-    using T = Tile<2, 1, 2, 4>;
-    if (pw) return a.pre_scale ? launch_conv_pre<T, true, false, 1, true>(a, st) : launch_conv_pre<T, false, false, 1, true>(a, st);
-    return a.pre_scale ? launch_conv_pre<T, true, false, 0, true>(a, st) : launch_conv_pre<T, false, false, 0, true>(a, st);
-  }
+  // (four waves of 128 x 32 instead -- half the B loads, twice the A reads -- measured the same: 178 vs 183 TFLOP/s)
+  if (bf3p_applies(a)) return launch_conv_pre<Tile<2, 2, 2, 2>, false, false, 13, true>(a, st);
   return launch_conv<Tile<1, 1>>(a, st);
 }
 

@@ -244,7 +244,7 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t by
 constexpr uint32_t OOB = 0xFFFFFFF0u;   // byte offset guaranteed past any descriptor's range
 
 // ------------------------------------------------------------------------------------------
-// Split-bf16 ("bf16x3") mainloop: the throughput mode behind dif_net_set_option("bf16x3").
+// Split-bf16 ("bf16x3") arithmetic: the throughput mode behind dif_net_set_option("bf16x3").
 //
 // Every f32 operand is written as hi + mid + lo, three bf16 terms obtained by repeated
 // round-to-nearest (x -> hi; x - hi -> mid; x - hi - mid -> lo: 3 x 8 significand bits, |error| <= 2^-24 |x|),
@@ -252,28 +252,12 @@ constexpr uint32_t OOB = 0xFFFFFFF0u;   // byte offset guaranteed past any descr
 //     lo.hi + hi.lo + mid.mid + mid.hi + hi.mid + hi.hi        (dropped: mid.lo, lo.mid, lo.lo <= 2^-24 |a||b|)
 // on v_mfma_f32_32x32x16_bf16 (16 K-values per instruction at half the cycles of the f32 MFMA's 2): 16/6 = 2.67x
 // the f32-MFMA ceiling for the same algorithmic work, at f32-level accuracy (tests: the same 1e-5 cosine gate).
-// Not bit-identical to an f32 fma chain, which is why it is a mode and not the default.
-//
-// Block = 8 waves, each 64x32 (WM = 2, WN = 1), K-step 32.  A is gathered as f32 (the same loaders as the f32
-// path, pre-activation included), split while it is staged; B (weights) is split once at finalize and lies in
-// HBM as [Cout][K/32][plane][32] bf16, so a row's K-step is one 192-byte run.  LDS image of either operand:
-// [row][3 planes][32 bf16] + 16 bytes of padding = 208-byte rows (52 dwords: a 16-lane ds_read_b128 group touches
-// 16 distinct multiples of 4 banks -- conflict-free); ONE buffer (two would not leave room for two blocks
-// per CU), hence two barriers per K-step: the second block on the CU computes while this one stages.
+// Not bit-identical to an f32 fma chain, which is why it is a mode and not the default.  The kernel is conv.hip's
+// gemm_mainloop_patch_bf3 (3x3 / stride 1 layers; every other layer stays on the f32 kernels).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-
-constexpr int BF3_ROWB = 208;        // bytes per LDS row
-constexpr int BF3_KSTEP_BYTES = 192; // bytes per (row, K-step) of pre-split weights in HBM
-
-template <class T>
-struct Bf3 {
-  static constexpr int MAIN_BYTES = (T::BM + T::BN) * BF3_ROWB;
-  static constexpr int EPI_BYTES = T::BM * (T::BN + 4) * 4;        // conv_epilogue's accumulator staging
-  static constexpr int LDS_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
-};
 
 __device__ __forceinline__ uint32_t bf3_cvt2(float a, float b) {   // v_cvt_pk_bf16_f32: round to nearest even
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2));
@@ -291,119 +275,6 @@ __device__ __forceinline__ void bf3_split(const f32x4& v, u32x2& hi, u32x2& mid,
   r2 -= bf3_lo(mid[1]);
   r3 -= bf3_hi(mid[1]);
   lo = u32x2{bf3_cvt2(r0, r1), bf3_cvt2(r2, r3)};
-}
-
-// Pre-split weights of one N tile: [rows][KS][3][32] bf16.  16-byte chunks, BN * 12 of them per K-step.
-template <class T>
-struct Bf3WeightLoader {
-  static constexpr int TOTAL = T::BN * 12, NCH = (TOTAL + T::NT - 1) / T::NT;
-  __amdgpu_buffer_rsrc_t rsrc;
-  uint32_t goff[NCH];   // byte offset of the chunk at K-step 0, or OOB
-  int loff[NCH];        // byte offset inside the B image in LDS, or -1
-  __device__ __forceinline__ Bf3WeightLoader(const char* tile_base, int64_t rows_left, int KS) {
-    const int64_t rows = rows_left < T::BN ? rows_left : T::BN;
-    rsrc = make_rsrc(tile_base, (uint32_t)(rows * KS * BF3_KSTEP_BYTES));
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-      const int q = threadIdx.x + T::NT * j;
-      const int row = q / 12, c = q - row * 12;
-      const bool on = q < TOTAL;
-      goff[j] = on ? (uint32_t)row * (uint32_t)KS * BF3_KSTEP_BYTES + (uint32_t)c * 16u : OOB;
-      loff[j] = on ? row * BF3_ROWB + c * 16 : -1;
-    }
-  }
-  __device__ __forceinline__ void load(int kstep, u32x4 (&r)[NCH]) const {
-#pragma unroll
-    for (int j = 0; j < NCH; ++j)
-      r[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[j] == OOB ? OOB : goff[j] + (uint32_t)kstep * BF3_KSTEP_BYTES, 0, 0);
-  }
-  __device__ __forceinline__ void store(char* lds_b, const u32x4 (&r)[NCH]) const {
-#pragma unroll
-    for (int j = 0; j < NCH; ++j)
-      if (loff[j] >= 0) *reinterpret_cast<u32x4*>(lds_b + loff[j]) = r[j];
-  }
-};
-
-template <class T, class ALoader, class BLoader, class Tail>
-__device__ __forceinline__ void gemm_mainloop_bf3(ALoader& al, BLoader& bl, int kbeg, int kend, char* lds,
-                                                  f32x16 (&acc)[T::WM][T::WN], Tail&& tail) {
-  constexpr int WM = T::WM, WN = T::WN, NA = T::NA, RP = T::RP;
-  constexpr int OFFB = T::BM * BF3_ROWB;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wr = T::wave_row(), wc = T::wave_col();
-  const int sa_off = (tid >> 3) * BF3_ROWB + (tid & 7) * 8;             // A staging: row (tid>>3) + RP*i, k = 4*(tid&7)..+3
-  const int fr_off = (lane & 31) * BF3_ROWB + (lane >> 5) * 16;         // fragment: row lane&31, k = 8*(lane>>5)..+7 of a 16-k sub-step
-  const char* pa = lds + (wr * WM * 32) * BF3_ROWB + fr_off;
-  const char* pb = lds + OFFB + (wc * WN * 32) * BF3_ROWB + fr_off;
-
-  f32x4 ra[NA];
-  u32x4 rb[BLoader::NCH];
-  auto stage = [&] {
-    al.finish(ra);
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      u32x2 hi, mid, lo;
-      bf3_split(ra[i], hi, mid, lo);
-      char* w = lds + sa_off + i * RP * BF3_ROWB;
-      *reinterpret_cast<u32x2*>(w) = hi;
-      *reinterpret_cast<u32x2*>(w + 64) = mid;
-      *reinterpret_cast<u32x2*>(w + 128) = lo;
-    }
-    bl.store(lds + OFFB, rb);
-  };
-  auto mfma_step = [&] {
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8 fa[WM][3], fb[WN][3];
-#pragma unroll
-      for (int m = 0; m < WM; ++m)
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-          fa[m][p] = *reinterpret_cast<const bf16x8*>(pa + m * 32 * BF3_ROWB + p * 64 + s * 32);
-#pragma unroll
-      for (int n = 0; n < WN; ++n)
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-          fb[n][p] = *reinterpret_cast<const bf16x8*>(pb + n * 32 * BF3_ROWB + p * 64 + s * 32);
-      // all fragment reads of the sub-step are in flight before its first MFMA: left alone, the scheduler
-      // recycles four fragment registers and puts a full LDS round trip (s_waitcnt lgkmcnt(0)) in front of
-      // almost every MFMA
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int m = 0; m < WM; ++m)
-#pragma unroll
-        for (int n = 0; n < WN; ++n) {
-          f32x16 c = acc[m][n];
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m][2], fb[n][0], c, 0, 0, 0);   // lo  . hi
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m][0], fb[n][2], c, 0, 0, 0);   // hi  . lo
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m][1], fb[n][1], c, 0, 0, 0);   // mid . mid
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m][1], fb[n][0], c, 0, 0, 0);   // mid . hi
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m][0], fb[n][1], c, 0, 0, 0);   // hi  . mid
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m][0], fb[n][0], c, 0, 0, 0);   // hi  . hi
-          acc[m][n] = c;
-        }
-    }
-  };
-  al.load(kbeg, ra);
-  bl.load(kbeg, rb);
-  int ks = kbeg;
-  for (; ks + 1 < kend; ++ks) {
-    stage();
-    __syncthreads();
-    al.load(ks + 1, ra);
-    bl.load(ks + 1, rb);
-    __builtin_amdgcn_sched_barrier(0);   // the prefetch stays above the MFMAs
-    mfma_step();
-    __syncthreads();   // every wave is done reading before the next K-step overwrites the image
-  }
-  // last K-step peeled: the caller's tail loads (the shortcut tile) hide behind its MFMAs, and their
-  // registers are not live through the loop
-  stage();
-  __syncthreads();
-  tail();
-  __builtin_amdgcn_sched_barrier(0);
-  mfma_step();
-  __syncthreads();
 }
 
 

@@ -15,6 +15,7 @@
 #include "net.hpp"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -886,6 +887,7 @@ int Net::set_option(const char* key, int value) {
     return use_bdp = value, 0;
   }
   if (!strcmp(key, "stem")) return use_stem = value != 0, 0;
+  if (!strcmp(key, "dbg")) return conv_dbg = value, 0;
   if (!strcmp(key, "patch")) return flag(CONV_OFF_PATCH);
   if (!strcmp(key, "patch2d")) return flag(CONV_OFF_PATCH2D);
   if (!strcmp(key, "bd")) return flag(CONV_OFF_BD);
@@ -956,11 +958,44 @@ int Net::finalize(int mb) {
         if (upload(this, params[op.w].data, &op.d_w_raw)) return -1;
         op.stem_mfma = true;
       }
+      op.d_w3f = nullptr;
+      op.w3f_bytes = 0;
+      if (compute_bf16x3 && op.k_order == 1 && op.KH == 3 && op.KW == 3 && op.stride == 1 && op.pad_t == 1 && op.pad_l == 1 &&
+          !op.pre_bn.valid() && op.Cout >= 128) {
+        // split-bf16 mode, fragment order: [Cout/32][KS][s 2][plane 3][lane 64][8 bf16]
+        const int KS = op.Kpad / BK, NT32 = (op.Cout + 31) / 32;
+        std::vector<uint16_t> wf((size_t)NT32 * KS * 3072, 0);
+        size_t o = 0;
+        for (int nt = 0; nt < NT32; ++nt)
+          for (int ks = 0; ks < KS; ++ks)
+            for (int s2 = 0; s2 < 2; ++s2) {
+              uint16_t* blk = wf.data() + o;
+              o += 3 * 512;
+              for (int ln = 0; ln < 64; ++ln)
+                for (int t = 0; t < 8; ++t) {
+                  const int row = nt * 32 + (ln & 31);
+                  float r = row < op.Cout ? packed[(size_t)row * op.Kpad + (size_t)ks * BK + 16 * s2 + 8 * (ln >> 5) + t] : 0.f;
+                  for (int p3 = 0; p3 < 3; ++p3) {
+                    const uint16_t b = f32_to_bf16_rne(r);
+                    blk[p3 * 512 + ln * 8 + t] = b;
+                    r -= bf16_to_f32(b);
+                  }
+                }
+            }
+        if ((uint64_t)wf.size() * 2 < 0xFFFFFFF0ull) {
+          void* d = nullptr;
+          DIF_HIP(hipMalloc(&d, wf.size() * sizeof(uint16_t)));
+          allocs.push_back(d);
+          DIF_HIP(hipMemcpy(d, wf.data(), wf.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+          op.d_w3f = d;
+          op.w3f_bytes = (uint32_t)(wf.size() * sizeof(uint16_t));
+        }
+      }
       // fragment-order copy for the B-direct patch mainloop (conv.hip: gemm_mainloop_patch_bd): every layer the patch paths
       // can take (3x3 / stride 1 / pad 1, whole 32-channel slices)
       op.d_w_frag = nullptr;
       op.w_frag_bytes = 0;
-      if (!compute_bf16x3 && op.k_order == 1 && op.KH == 3 && op.KW == 3 && op.stride == 1 && op.pad_t == 1 && op.pad_l == 1 &&
+      if (!op.d_w3f && op.k_order == 1 && op.KH == 3 && op.KW == 3 && op.stride == 1 && op.pad_t == 1 && op.pad_l == 1 &&
           !op.pre_bn.valid()) {
         const int KS = op.Kpad / BK, NT32 = (op.Cout + 31) / 32;
         std::vector<float> frag((size_t)NT32 * 32 * op.Kpad, 0.f);
@@ -979,27 +1014,6 @@ int Net::finalize(int mb) {
           if (upload(this, frag, &op.d_w_frag)) return -1;
           op.w_frag_bytes = (uint32_t)(frag.size() * 4);
         }
-      }
-      op.d_w3 = nullptr;
-      if (compute_bf16x3 && op.Cin % BK == 0 && op.Cout >= 32 && op.Cout % 4 == 0) {
-        // split-bf16 mode: hi / mid / lo planes by repeated round-to-nearest-even, [Cout][Kpad/32][3][32]
-        std::vector<uint16_t> w3((size_t)op.Cout * op.Kpad * 3);
-        const int KS = op.Kpad / BK;
-        for (int co = 0; co < op.Cout; ++co)
-          for (int ks = 0; ks < KS; ++ks)
-            for (int k = 0; k < BK; ++k) {
-              float r = packed[(size_t)co * op.Kpad + (size_t)ks * BK + k];
-              for (int p = 0; p < 3; ++p) {
-                const uint16_t b = f32_to_bf16_rne(r);
-                w3[(((size_t)co * KS + ks) * 3 + p) * BK + k] = b;
-                r -= bf16_to_f32(b);
-              }
-            }
-        void* d = nullptr;
-        DIF_HIP(hipMalloc(&d, w3.size() * sizeof(uint16_t) + 64));
-        allocs.push_back(d);
-        DIF_HIP(hipMemcpy(d, w3.data(), w3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-        op.d_w3 = d;
       }
       fold(this, op.bn, op.bias, op.Cout, &scale, &shift);
       if (!scale.empty() && upload(this, scale, &op.d_scale)) return -1;
@@ -1204,7 +1218,8 @@ int Net::run_op(const Op& op, Lane& L, const void* xin, int n, int layout, int d
       memset(&a, 0, sizeof(a));
       a.x = ptr(op.x);
       a.w = op.d_w;
-      a.w3 = op.d_w3;
+      a.w3f = op.d_w3f;
+      a.w3f_bytes = op.w3f_bytes;
       a.w_frag = op.d_w_frag;
       a.w_frag_bytes = op.w_frag_bytes;
       a.y = ptr(op.y);
@@ -1271,6 +1286,7 @@ int Net::run_op(const Op& op, Lane& L, const void* xin, int n, int layout, int d
       a.sk_spin_limit = sk_spin_limit;
       a.use_pipe = use_pipe;
       a.off = conv_off;
+      a.dbg = conv_dbg;
       a.bdp_mode = use_bdp == 2 ? 2 : ((use_bdp == 0 || lane_split) ? 1 : 0);
       a.trace = trace_buf ? trace_buf + trace_off[&op - ops.data()] * 8 : nullptr;
       if (op.d_w_raw && op.stem_mfma && use_stem) {
@@ -1475,6 +1491,39 @@ int Net::embed_clock(const void* xin, int n, int layout, int dtype, float* out, 
   }
   (void)hipFree(d);
   if (rc) return rc;
+  if (conv_dbg & 256) {
+    // development aid: per convolution, what its blocks did (100 MHz ticks -> us): the launch's span, the blocks' lifetimes,
+    // and for conv_igemm_kernel records the time in mainloops / partial-tile hand-over / epilogues
+    for (size_t i = 0; i < ops.size(); ++i) {
+      if (ops[i].kind != OP_CONV) continue;
+      const size_t end = i + 1 < ops.size() ? trace_off[i + 1] : total;
+      unsigned long long t_lo = ~0ull, t_hi = 0;
+      double life = 0, mn = 1e30, mx = 0, m = 0, f = 0, e = 0, steps = 0, tiles = 0;
+      int nb = 0;
+      for (size_t b = trace_off[i]; b < end; ++b) {
+        const unsigned long long* t = &h[b * 8];
+        if ((t[7] & 0xff) == 0 || t[6] <= t[5]) continue;
+        ++nb;
+        t_lo = t[5] < t_lo ? t[5] : t_lo;
+        t_hi = t[6] > t_hi ? t[6] : t_hi;
+        const double l = (double)(t[6] - t[5]);
+        life += l;
+        mn = l < mn ? l : mn;
+        mx = l > mx ? l : mx;
+        if ((t[7] & 0xff) == 1) {
+          m += (double)t[0];
+          f += (double)t[1];
+          e += (double)t[2];
+          steps += (double)t[3];
+          tiles += (double)t[4];
+        }
+      }
+      if (nb)
+        fprintf(stderr, "trace %-22s blocks %5d span %7.1f us | life mean %7.1f min %7.1f max %7.1f | main %6.1f fix %6.1f epi %6.1f us/block | "
+                        "steps/block %.1f tiles/block %.2f\n", ops[i].name.c_str(), nb, (double)(t_hi - t_lo) / 100.0, life / nb / 100.0,
+                mn / 100.0, mx / 100.0, m / nb / 100.0, f / nb / 100.0, e / nb / 100.0, steps / nb, tiles / nb);
+    }
+  }
   double cyc = 0, ticks = 0;
   for (size_t b = 0; b < total; ++b) {
     const unsigned long long* t = &h[b * 8];

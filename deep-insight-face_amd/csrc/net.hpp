@@ -69,7 +69,8 @@ struct Op {
   float* d_w_dense = nullptr;
   float* d_w_frag = nullptr;  // the matrix in MFMA-fragment order (ConvArgs::w_frag), 3x3 / stride 1 layers on the f32 path
   uint32_t w_frag_bytes = 0;
-  void* d_w3 = nullptr;       // split-bf16 planes of the same matrix (compute mode bf16x3)
+  void* d_w3f = nullptr;      // compute mode bf16x3: the split-bf16 planes in MFMA-fragment order (ConvArgs::w3f), 3x3 / stride 1 layers
+  uint32_t w3f_bytes = 0;
   float* d_scale = nullptr;
   float* d_shift = nullptr;
   float* d_alpha = nullptr;
@@ -136,6 +137,7 @@ struct Net {
   int use_stem = 1;                 // option "stem": 0 runs 3-channel first layers on conv_igemm_kernel too
   int use_ysub = 1;                 // option "ysub" (before finalize): 0 keeps outputs read only at stride 2 dense
   int opt_lane_split = -1;          // option "lane_split" (before finalize): -1 by work per launch, 0 / 1 forced
+  int conv_dbg = 0;                 // option "dbg": ConvArgs::dbg
   unsigned conv_off = 0;            // options "patch", "patch2d", "bd" = 0: CONV_OFF_* bits handed to every convolution
   int set_option(const char* key, int value);   // dif_net_set_option; also applied from DIF_OPTIONS="key=value,..." at finalize
 

@@ -46,7 +46,8 @@ struct ConvArgs {
   const float* w_frag;  // the same matrix in MFMA-fragment order for the B-direct patch mainloop (conv.hip), or null:
                         // [ceil(Cout/32)][Kpad/32][s 2][u 2][h 2][n 32][t 4] <- w[32 nt + n][32 ks + 16 s + 8 h + 4 u + t]
   uint32_t w_frag_bytes;
-  const void* w3;       // split-bf16 mode: the same matrix as three bf16 planes, [Cout][Kpad/32][3][32] (null: f32 path)
+  const void* w3f;      // split-bf16 mode, 3x3 / stride 1 layers: the three bf16 planes in MFMA-fragment order (conv.hip:
+  uint32_t w3f_bytes;   // gemm_mainloop_patch_bf3), [ceil(Cout/32)][Kpad/32][s 2][plane 3][lane 64][8]
   int k_order;          // 0: k = (kh*KW + kw)*Cin + ci (tap-major)
                         // 1: k = ((ci/32)*KH*KW + kh*KW + kw)*32 + ci%32 (channel-block-major, Cin % 32 == 0):
                         //    consecutive K-steps sweep the taps of ONE 32-channel slice, i.e. re-read the
@@ -90,6 +91,7 @@ struct ConvArgs {
                         // launches are short and the lanes run half-chip grids: measured 1-2 % slower there; Net option
                         // "bdp" = 0), 2 wherever its restrictions allow (Net option "bdp" = 2: the parity tests)
   int use_pipe;         // 0: never take the software-pipelined kernel (Net option "pipe"; tests compare both paths)
+  int dbg;              // development aid (ablation bits of the kernel under work); 0 in production
   unsigned off;         // kernel families switched off (Net options "patch", "patch2d", "bd" = 0): CONV_OFF_* bits
   // development aid (tools/ubench/conv_trace.hip), null in the library: 4 x u64 per hardware block =
   // s_memrealtime (100 MHz) at entry / after the first mainloop / at exit, and the HW_ID register
