@@ -246,7 +246,8 @@ def test_wrapper_resizes_off_size_crops_on_the_device(cuda, model):
         want = oi.area_resize(img, 112)
         diff = np.abs(got.cpu().numpy().astype(np.int32) - want.astype(np.int32))
         # exact ties at .5 are common at rational ratios (160 -> 112: values are k/100) and round differently in float32 and float64
-        assert diff.max() <= 1 and (diff > 0).mean() < 0.02, (shape, diff.max(), (diff > 0).mean())
+        # (enlarging 96 -> 112 every value is k/36: half-way cases are one in twelve)
+        assert diff.max() <= 1 and (diff > 0).mean() < (0.10 if min(shape) < 112 else 0.02), (shape, diff.max(), (diff > 0).mean())
         emb = tp._embedding(img)
         assert isinstance(emb, np.ndarray) and emb.shape == (1, 128)
         ref = nets.embed(want[None].astype(np.float32) / np.float32(255), p, 'resnet', 128, 'v2')
