@@ -287,6 +287,7 @@ def main():
     ap.add_argument('--batch', type=int, default=0, help='per-GPU batch override')
     ap.add_argument('--gallery', type=int, default=0, help='total gallery rows override')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-throughput-mode', action='store_true', help='skip the extra split-bf16 forward timing')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='gloo = rehearsal of the N>1 path on a box with fewer GPUs than ranks (collectives staged '
                          'through the host, ranks share devices); never used for reported numbers')
@@ -543,6 +544,33 @@ def main():
                                        'faces_per_s_embed_only': 256 / (b256_ms * 1e-3),
                                        'traffic': measured_traffic('r100', 256),
                                        'note': 'north_star target configuration: IResNet-100 forward at batch 256'}
+        if world == 1 and pipe is None and compute == 'f32' and arch.startswith('iresnet') and not args.no_throughput_mode:
+            # the split-bf16 THROUGHPUT mode on the same crops, weights and batch (never the headline: `value` above is float32,
+            # the reference's arithmetic): forward time, and its cosine gap to the float32 embeddings of this very run
+            b3 = DifEmbedder(arch, head, 512, (112, 112, 3), max_batch=batch, compute='bf16x3')
+            b3.set_weights(model.get_weights())
+            b3.set_input_transform(scale=1 / 255.)
+            e3 = b3.embed(crops)
+            for _ in range(3):
+                b3.embed(crops)
+            reps = max(3, min(args.steps, 10))
+            tv = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            tv[0].record()
+            for _ in range(reps):
+                b3.embed(crops)
+            tv[1].record()
+            torch.cuda.synchronize()
+            ms3 = tv[0].elapsed_time(tv[1]) / reps
+            ef, e3d = emb_buf.double(), e3.double()
+            gap = float((1 - (ef * e3d).sum(1) / (ef.norm(dim=1) * e3d.norm(dim=1))).max())
+            out['throughput_mode'] = {
+                'compute': 'bf16x3 (three bf16 terms per f32 operand, six bf16 MFMA products, f32 accumulation; 3x3 / stride 1 '
+                           'layers from 128 channels up, the other layers stay float32)',
+                'forward_ms_hip_events': ms3, 'faces_per_s_embed_only': batch / (ms3 * 1e-3),
+                'faces_per_s_with_the_float32_runs_match': batch / ((ms3 + match_ms) * 1e-3),
+                'algorithmic_tflops': flops_embed / (ms3 * 1e-3) / 1e12, 'speedup_vs_float32_forward': embed_ms / ms3,
+                'max_cosine_gap_to_float32_embeddings': gap}
+            b3.close()
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = (cpu_baseline(arch, head, gallery_rows) if pipe is None else
                                    cpu_baseline_frames(gallery_rows, dp))

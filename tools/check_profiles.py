@@ -1,4 +1,4 @@
-"""Copies the round-2 rocprofv3 summaries from gpurun_out/r02/ into profiles/ and prints the cross-checks
+"""Copies the round-3 rocprofv3 summaries from gpurun_out/r03/ into profiles/ and prints the cross-checks
 the bench line's `roofline` rests on: per forward, the sum of the conv kernel durations in the kernel-trace stats
 (one lane: no overlap) vs the HIP-event forward time reported by bench.py, and the frac recomputed from them."""
 import csv
@@ -9,9 +9,9 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, 'gpurun_out', 'r02')
+OUT = os.path.join(ROOT, 'gpurun_out', 'r03')
 PROF = os.path.join(ROOT, 'profiles')
-R = 'r02'
+R = 'r03'
 PEAK = 157.3
 
 
@@ -70,6 +70,10 @@ def main():
                             os.path.join(OUT, 'pw_r50/p_counter_collection.csv'), '%g' % equiv_forwards('pf_r50', 256)],
          R + '_r50_b256_hbm_traffic.json')
     tool('pmc_mfma.py', [os.path.join(OUT, 'pm_default/p_counter_collection.csv')], R + '_r100_1m_mfma_util.json')
+    tool('pmc_mfma.py', [os.path.join(OUT, 'pm_bf16x3/p_counter_collection.csv')], R + '_r100_1m_bf16x3_mfma_util.json')
+    for src, dst in (('trace_r100_f32.txt', '_r100_b256_block_trace.txt'), ('trace_r100_bf16x3.txt', '_r100_b256_bf16x3_block_trace.txt')):
+        with open(os.path.join(OUT, src)) as fh, open(os.path.join(PROF, R + dst), 'w') as out:
+            out.writelines(l for l in fh if l.startswith('trace '))
 
     # cross-check 1: default workload, ONE lane: every forward of the profiled process, in batch-512 equivalents
     one = jl(os.path.join(OUT, 'ks_default_1lane.json'))

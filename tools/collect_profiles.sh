@@ -1,11 +1,11 @@
 #!/bin/bash
-# Round-2 evidence run, on the GPU box (via gpurun): rocprofv3 kernel-trace stats of the EXACT driver command
+# Round-3 evidence run, on the GPU box (via gpurun): rocprofv3 kernel-trace stats of the EXACT driver command
 # (python3 bench.py --gpus 1 --steps 20 --warmup 5), separate PMC passes (never combined with tracing), the
 # un-profiled bench lines of every workload, per-layer tables and the small-batch latency table.
-# Outputs land in gpurun_out/r02/; tools/check_profiles.py copies the summaries into profiles/.
+# Outputs land in gpurun_out/r03/; tools/check_profiles.py copies the summaries into profiles/.
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r02
+O=gpurun_out/r03
 mkdir -p $O
 prof() { local tag=$1; shift; rocprofv3 "$@" --output-format csv -d $O/$tag -o p -- python3 bench.py --gpus 1 ${ARGS} > $O/$tag.json 2> $O/$tag.err; }
 # 1. the driver's command, default executor (two lanes: kernel durations of the two streams overlap)
@@ -35,5 +35,8 @@ python3 tools/layer_profile.py iresnet100 256 > $O/layers_r100.txt 2>&1 &&
 python3 tools/layer_profile.py resnet 256 > $O/layers_r50.txt 2>&1 &&
 python3 tools/layer_profile.py iresnet100 256 bf16x3 > $O/layers_r100_bf16x3.txt 2>&1 &&
 python3 tools/layer_profile.py yolov3 64 > $O/layers_yolov3.txt 2>&1 &&
-python3 tools/latency.py > $O/latency.txt 2>&1
+python3 tools/latency.py > $O/latency.txt 2>&1 &&
+DIF_STREAMS=1 ARGS="--workload r100_1m_bf16x3 --steps 3 --warmup 1 --no-cpu-baseline" prof pm_bf16x3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE &&
+DIF_OPTIONS=dbg=256 python3 tools/bf3_trace.py 256 f32 2> $O/trace_r100_f32.txt > /dev/null &&
+DIF_OPTIONS=dbg=256 python3 tools/bf3_trace.py 256 bf16x3 2> $O/trace_r100_bf16x3.txt > /dev/null
 echo "collect rc=$?"
