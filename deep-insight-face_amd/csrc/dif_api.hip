@@ -73,6 +73,8 @@ int dif_gallery_destroy(dif_gallery* h) {
   if (!h) return 0;
   Gallery& g = h->g;
   if (g.rows) (void)hipFree(g.rows);
+  if (g.rows2) (void)hipFree(g.rows2);
+  if (g.probes2) (void)hipFree(g.probes2);
   if (g.sq) (void)hipFree(g.sq);
   if (g.ninv) (void)hipFree(g.ninv);
   for (void* p : {(void*)g.part_key, (void*)g.part_cnt, (void*)g.part_idx, (void*)g.eps, (void*)g.best,
@@ -93,11 +95,13 @@ int dif_gallery_set(dif_gallery* h, const float* rows_dev, int64_t n, int64_t in
   if (n > g.cap) {
     DIF_HIP(hipStreamSynchronize(st));
     if (g.rows) DIF_HIP(hipFree(g.rows));
+    if (g.rows2) DIF_HIP(hipFree(g.rows2));
     if (g.sq) DIF_HIP(hipFree(g.sq));
     if (g.ninv) DIF_HIP(hipFree(g.ninv));
-    g.rows = g.sq = g.ninv = nullptr;
+    g.rows = g.rows2 = g.sq = g.ninv = nullptr;
     g.cap = 0;
     DIF_HIP(hipMalloc(&g.rows, (size_t)n * g.d * sizeof(float)));
+    DIF_HIP(hipMalloc(&g.rows2, (size_t)n * g.d * sizeof(float)));
     DIF_HIP(hipMalloc(&g.sq, (size_t)n * sizeof(float)));
     DIF_HIP(hipMalloc(&g.ninv, (size_t)n * sizeof(float)));
     g.cap = n;
@@ -115,6 +119,10 @@ int dif_gallery_set_option(dif_gallery* h, const char* key, int value) {
   if (!h || !key) return set_error("dif_gallery_set_option: null argument");
   if (std::string(key) == "clamp_nan") {
     h->g.clamp_nan = value != 0;
+    return 0;
+  }
+  if (std::string(key) == "filter") {
+    h->g.filter_bf2 = value != 0;
     return 0;
   }
   return set_error("dif_gallery_set_option: unknown key '%s'", key);

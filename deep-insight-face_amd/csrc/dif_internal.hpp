@@ -22,6 +22,8 @@ struct Gallery {
   int64_t cap = 0;
   int64_t index_base = 0;   // global index of row 0 (gallery sharded across ranks)
   float* rows = nullptr;    // [n][d]
+  float* rows2 = nullptr;   // the same rows as two bf16 planes per K-step of 32, [n][d/32][hi 32 | mid 32] (the filter's operand)
+  float* probes2 = nullptr; // this call's probes in the same form (probe_cap rows)
   float* sq = nullptr;      // |g|^2
   float* ninv = nullptr;    // -1/|g|
   // match workspace (csrc/match.hip): per (block, probe) minimum key, candidate count, candidate rows
@@ -42,6 +44,7 @@ struct Gallery {
   int* nflag = nullptr;            // number of probes sent to the exact search in the current call
   unsigned* sqmax_bits = nullptr;  // bits of max |g|^2 over the rows the metric-0 filter sees
   struct GalleryFlags* flags = nullptr;   // rows the filter cannot rank (csrc/match.hip), found by gallery_norms
+  bool filter_bf2 = true;          // the MFMA filter runs on two-term split-bf16 operands (dif_gallery_set_option "filter" = 0: f32)
   bool clamp_nan = false;          // report distance 0 / 1 instead of the reference's NaN (dif_gallery_set_option)
 };
 

@@ -278,6 +278,78 @@ __device__ __forceinline__ void bf3_split(const f32x4& v, u32x2& hi, u32x2& mid,
 }
 
 
+// ------------------------------------------------------------------------------------------
+// Two-term split-bf16 mainloop ("bf16x2"): the search-key FILTER of the gallery match (match.hip), nowhere else.
+// Both operands lie in memory ALREADY split, in the byte layout of the f32 matrix they stand for: per row and K-step of
+// 32 values, [hi: 32 bf16][mid: 32 bf16] = the same 128 bytes, so the f32 row loaders and the 144-byte LDS rows serve
+// unchanged.  x = hi + mid + O(2^-18 |x|); a . b ~ mid.hi + hi.mid + hi.hi (dropped: mid.mid <= 2^-18 |a||b|) on
+// v_mfma_f32_32x32x16_bf16, three MFMAs of 32 cycles per 16 k against eight of 64 cycles on the f32 MFMA: 5.3x less
+// matrix time for a dot product good to ~1e-5 |a||b| -- which is all a filter with a proven error bound needs.
+template <class T, class ALoader, class BLoader>
+__device__ __forceinline__ void gemm_mainloop_bf2(ALoader& al, BLoader& bl, int kbeg, int kend, float* lds,
+                                                  f32x16 (&acc)[T::WM][T::WN]) {
+  constexpr int WM = T::WM, WN = T::WN, BM = T::BM, BN = T::BN, NA = T::NA, NB = T::NB, RP = T::RP;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wr = T::wave_row(), wc = T::wave_col();
+  constexpr int BUF = (BM + BN) * LDS_STRIDE, OFFB = BM * LDS_STRIDE;
+  const int st_off = (tid >> 3) * LDS_STRIDE + (tid & 7) * 4;
+  const int fr_off = (lane & 31) * LDS_STRIDE + 4 * (lane >> 5);     // floats: row lane & 31, byte 16 (lane >> 5) of a plane's 16-k half
+  f32x4 ra[NA], rb[NB];
+  al.load(kbeg, ra);
+  bl.load(kbeg, rb);
+#pragma unroll
+  for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(lds + st_off + i * RP * LDS_STRIDE) = ra[i];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(lds + OFFB + st_off + i * RP * LDS_STRIDE) = rb[i];
+  __syncthreads();
+  for (int ks = kbeg; ks < kend; ++ks) {
+    const int cur = (ks - kbeg) & 1;
+    const bool more = ks + 1 < kend;
+    if (more) {
+      al.load(ks + 1, ra);
+      bl.load(ks + 1, rb);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const float* pa = lds + cur * BUF + (wr * WM * 32) * LDS_STRIDE + fr_off;
+    const float* pb = lds + cur * BUF + OFFB + (wc * WN * 32) * LDS_STRIDE + fr_off;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 ah[WM], am[WM], bh[WN], bm[WN];
+#pragma unroll
+      for (int m = 0; m < WM; ++m) {
+        ah[m] = *reinterpret_cast<const bf16x8*>(pa + m * 32 * LDS_STRIDE + 8 * s);
+        am[m] = *reinterpret_cast<const bf16x8*>(pa + m * 32 * LDS_STRIDE + 16 + 8 * s);
+      }
+#pragma unroll
+      for (int n = 0; n < WN; ++n) {
+        bh[n] = *reinterpret_cast<const bf16x8*>(pb + n * 32 * LDS_STRIDE + 8 * s);
+        bm[n] = *reinterpret_cast<const bf16x8*>(pb + n * 32 * LDS_STRIDE + 16 + 8 * s);
+      }
+#pragma unroll
+      for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int n = 0; n < WN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[m], bh[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int n = 0; n < WN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bm[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int n = 0; n < WN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+    }
+    if (more) {
+      float* wa = lds + (cur ^ 1) * BUF + st_off;
+      float* wb = lds + (cur ^ 1) * BUF + OFFB + st_off;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(wa + i * RP * LDS_STRIDE) = ra[i];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(wb + i * RP * LDS_STRIDE) = rb[i];
+    }
+    __syncthreads();
+  }
+}
+
 // Row-major [rows][ld] matrix, K contiguous; rows >= nrows read as zero.  Used for packed
 // convolution weights ([Cout][Kpad]), the gallery, the probes and the ArcMargin class
 // centres.  `base` points at the tile's first row (block-uniform), so byte offsets stay

@@ -42,7 +42,8 @@ class Gallery:
         return int(N.lib.dif_gallery_size(self._h))
 
     def set_option(self, key, value):
-        """'clamp_nan': 1 reports distance 0 / 1 where the reference's distance is NaN (a similarity rounded
+        """'filter': 0 runs the MFMA filter stage in float32 instead of two-term split-bf16 (same results).
+        'clamp_nan': 1 reports distance 0 / 1 where the reference's distance is NaN (a similarity rounded
         beyond +-1); the default 0 reports NaN like the reference.  The arg-min is unaffected."""
         N.check(N.lib.dif_gallery_set_option(self._h, key.encode(), int(value)), ValueError)
 

@@ -287,6 +287,14 @@ def test_match_near_ties_vs_golden(cuda, golden_dir, metric):
     for lo, hi in ((0, 1), (1, 34), (34, 48)):
         i2, _ = gal.match(probes[lo:hi], metric)
         assert np.array_equal(i2, g['idx%d' % metric][lo:hi])
+    # the filter stage on the f32 MFMA instead of the two-term split-bf16 default: the same answers, bit for bit (the
+    # filter only proposes candidates; the reference arithmetic decides)
+    gal.set_option('filter', 0)
+    i4, d4, k4 = gal.match(probes, metric, return_key=True)
+    assert np.array_equal(i4, idx) and np.array_equal(d4, dist, equal_nan=True) and np.array_equal(k4, key)
+    for lo, hi in ((0, 1), (1, 34), (34, 48)):
+        i2, _ = gal.match(probes[lo:hi], metric)
+        assert np.array_equal(i2, g['idx%d' % metric][lo:hi])
     gal.close()
 
 
@@ -344,10 +352,12 @@ def test_match_degenerate_vs_golden(cuda, golden_dir, name):
             assert np.array_equal(dist[~nan].view(np.uint32), want_d[~nan].view(np.uint32))
         elif (~nan).any():
             assert np.abs(dist[~nan].view(np.int32).astype(np.int64) - want_d[~nan].view(np.int32)).max() <= 4
-        # ragged groups of probes (other tile shapes)
-        for lo, hi in ((0, 1), (1, 12), (12, B)):
-            i2, _ = gal.match(probes[lo:hi], metric)
-            assert np.array_equal(i2, want_i[lo:hi]), (metric, lo, hi)
+        # ragged groups of probes (other tile shapes), on either filter (split-bf16 default, f32)
+        for flt in (0, 1):
+            gal.set_option('filter', flt)
+            for lo, hi in ((0, 1), (1, 12), (12, B)):
+                i2, _ = gal.match(probes[lo:hi], metric)
+                assert np.array_equal(i2, want_i[lo:hi]), (metric, lo, hi, flt)
         R = 3
         packed = torch.empty((R, 4 * B), dtype=torch.float32, device='cuda')
         for r in range(R):

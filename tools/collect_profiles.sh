@@ -11,13 +11,13 @@ prof() { local tag=$1; shift; rocprofv3 "$@" --output-format csv -d $O/$tag -o p
 # 1. the driver's command, default executor (two lanes: kernel durations of the two streams overlap)
 ARGS="--steps 20 --warmup 5" prof ks_default --kernel-trace --stats &&
 # 2. the same workload on ONE lane: kernels run back to back, so per-kernel durations add up to the forward
-DIF_STREAMS=1 ARGS="--steps 20 --warmup 5 --no-cpu-baseline" prof ks_default_1lane --kernel-trace --stats &&
+DIF_STREAMS=1 ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-throughput-mode" prof ks_default_1lane --kernel-trace --stats &&
 # 3. counters, each in its own pass
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline" prof pf_default --pmc FETCH_SIZE &&
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline" prof pw_default --pmc WRITE_SIZE &&
-DIF_STREAMS=1 ARGS="--steps 3 --warmup 1 --no-cpu-baseline" prof pm_default --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE &&
-ARGS="--workload r100 --steps 3 --warmup 1 --no-cpu-baseline" prof pf_r100 --pmc FETCH_SIZE &&
-ARGS="--workload r100 --steps 3 --warmup 1 --no-cpu-baseline" prof pw_r100 --pmc WRITE_SIZE &&
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-throughput-mode" prof pf_default --pmc FETCH_SIZE &&
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-throughput-mode" prof pw_default --pmc WRITE_SIZE &&
+DIF_STREAMS=1 ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-throughput-mode" prof pm_default --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE &&
+ARGS="--workload r100 --steps 3 --warmup 1 --no-cpu-baseline --no-throughput-mode" prof pf_r100 --pmc FETCH_SIZE &&
+ARGS="--workload r100 --steps 3 --warmup 1 --no-cpu-baseline --no-throughput-mode" prof pw_r100 --pmc WRITE_SIZE &&
 DIF_STREAMS=1 ARGS="--workload r50 --steps 10 --warmup 3 --no-cpu-baseline" prof ks_r50_1lane --kernel-trace --stats &&
 ARGS="--workload r50 --steps 3 --warmup 1 --no-cpu-baseline" prof pf_r50 --pmc FETCH_SIZE &&
 ARGS="--workload r50 --steps 3 --warmup 1 --no-cpu-baseline" prof pw_r50 --pmc WRITE_SIZE &&

@@ -1,0 +1,35 @@
+"""Development A/B: dif_match time at bench shapes, split-bf16 filter vs f32 filter."""
+import os
+import sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'deep-insight-face_amd'))
+from deep_insight_face import oneshot  # noqa: E402
+for G, B in ((1_000_000, 512), (100_000, 256), (125_000, 4096), (1_000_000, 32)):
+    g = torch.Generator(device='cuda').manual_seed(7)
+    gal = torch.nn.functional.normalize(torch.randn((G, 512), generator=g, device='cuda'), dim=1)
+    pick = torch.randperm(G, generator=g, device='cuda')[:B]
+    probes = torch.nn.functional.normalize(gal[pick] + 0.03 * torch.randn((B, 512), generator=g, device='cuda'), dim=1)
+    rnd = torch.nn.functional.normalize(torch.randn((B, 512), generator=g, device='cuda'), dim=1)     # no enrolment: impostor tails
+    G_ = oneshot.Gallery(gal)
+    idx = torch.empty(B, dtype=torch.int64, device='cuda')
+    dist = torch.empty(B, dtype=torch.float32, device='cuda')
+    res = {}
+    for flt in (0, 1):
+        G_.set_option('filter', flt)
+        for name, p in (('planted', probes), ('random', rnd)):
+            for _ in range(3):
+                G_.match_into(p, 1, idx, dist)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            ev[0].record()
+            for _ in range(10):
+                G_.match_into(p, 1, idx, dist)
+            ev[1].record()
+            torch.cuda.synchronize()
+            res[(flt, name)] = (ev[0].elapsed_time(ev[1]) / 10, idx.clone())
+    ok = torch.equal(res[(0, 'planted')][1], res[(1, 'planted')][1]) and torch.equal(res[(0, 'random')][1], res[(1, 'random')][1]) \
+        and torch.equal(res[(1, 'planted')][1], pick)
+    print('G=%d B=%d  f32 filter %.3f / %.3f ms   bf16x2 filter %.3f / %.3f ms (planted / random probes)  same answers: %s' % (
+        G, B, res[(0, 'planted')][0], res[(0, 'random')][0], res[(1, 'planted')][0], res[(1, 'random')][0], ok))
+    G_.close()
+    del gal
