@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'build')
 LIB = os.path.join(HERE, 'lib', 'libdif.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
+FLAGS = os.environ.get("DIF_EXTRA_FLAGS", "").split() + ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
          '-ffp-contract=off' if os.environ.get('DIF_NO_FMA') else '-ffp-contract=fast']
 
 

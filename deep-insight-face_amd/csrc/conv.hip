@@ -482,7 +482,7 @@ __device__ __forceinline__ void gemm_mainloop_patch(const PA& pa, BLoader& bl, i
   };
   pa.store(patch, pr);
   stage_b(0);
-  __syncthreads();
+  lds_barrier();
   bool pf_issued = false;
   auto mfma_step = [&](int cur) {
     const int kh = tap >= 6 ? 2 : (tap >= 3 ? 1 : 0);
@@ -517,15 +517,15 @@ __device__ __forceinline__ void gemm_mainloop_patch(const PA& pa, BLoader& bl, i
     if (++tap == 9) {
       tap = 0;
       ++cb;
-      __syncthreads();                                     // every wave has read its last fragment of the old patch
+      lds_barrier();                                     // every wave has read its last fragment of the old patch
       pa.store(patch, pr);     // pf_issued holds here: the slice had a successor, so its taps >= PF_TAP requested it
       pf_issued = false;
     }
-    __syncthreads();
+    lds_barrier();
   }
   tail();
   mfma_step((ks - kbeg) & 1);
-  __syncthreads();
+  lds_barrier();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -569,7 +569,7 @@ __device__ __forceinline__ void gemm_mainloop_patch_bd(const PA& pa, const ConvA
   pa.load(cb, pr);
   bload(kbeg, 0, bA);
   pa.store(patch, pr);
-  __syncthreads();
+  lds_barrier();
   bool pf_issued = false;
   const char* patch_b = reinterpret_cast<const char*>(patch);
   const uint32_t l0x = (uint32_t)(2 * h);                 // logical chunk of half 0, piece 0; the others are l0x | 1, | 4, | 5
@@ -624,10 +624,10 @@ __device__ __forceinline__ void gemm_mainloop_patch_bd(const PA& pa, const ConvA
       tap = 0;
       eoff = 0;
       ++cb;
-      __syncthreads();                                     // every wave has read its last fragment of the old patch
+      lds_barrier();                                     // every wave has read its last fragment of the old patch
       pa.store(patch, pr);
       pf_issued = false;
-      __syncthreads();
+      lds_barrier();
       a0 = frag_addr();
       read_frag(a0, 0, fa);
     }
@@ -639,7 +639,7 @@ __device__ __forceinline__ void gemm_mainloop_patch_bd(const PA& pa, const ConvA
   mfma8(fa, bA);
   mfma8(fn, bB);
   post();
-  __syncthreads();
+  lds_barrier();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -747,15 +747,6 @@ struct PatchDma {
   }
 };
 
-// LDS-only workgroup barrier: the fences name the local address space, so the compiler waits for this wave's LDS
-// operations (lgkmcnt) but leaves its global loads -- the B fragments requested ahead -- in flight across the barrier
-// (__syncthreads() drains vmcnt as well: the whole prefetch, at every patch swap)
-__device__ __forceinline__ void lds_barrier() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-
 // K-steps [9 cbeg, 9 cend): whole 32-channel slices (the kernel cuts its stream-K shares at slice boundaries).  One slice =
 // nine taps = 18 sub-steps of 24 MFMAs, written out as straight-line code: the tap is a compile-time constant (an immediate
 // address offset), nothing is carried through a branch, and three rings turn at fixed phase --
@@ -815,8 +806,9 @@ __device__ __forceinline__ void gemm_mainloop_patch_bf3(const PA& pa, const Conv
     for (int m = 0; m < WM; ++m) arow[m] = (uint32_t)(pa.base[m] + kh * pa.WP) * (uint32_t)BF3P_EB + (uint32_t)h * 16u;
   };
 
+  constexpr int FA_SETS = 2;     // A fragment sets: 2 = read one sub-step ahead, 1 = read right before their MFMAs
   u32x4 bq[3][WN][3];
-  u32x4 fa[2][WM][3];
+  u32x4 fa[FA_SETS][WM][3];
   pa.issue(cbeg, staging);
   bload(18 * cbeg, bq[0]);
   bload(18 * cbeg + 1, bq[1]);
@@ -827,21 +819,21 @@ __device__ __forceinline__ void gemm_mainloop_patch_bf3(const PA& pa, const Conv
   for (int cb = cbeg; cb < cend; ++cb) {
     const int u0 = 18 * cb;
     set_row(0);
-    aread(0, 0, fa[0]);
+    if constexpr (FA_SETS == 2) aread(0, 0, fa[0]);
     // sub-step I of the slice (compile time): tap I / 2, half I % 2
     auto substep = [&](auto ic) {
       constexpr int I = decltype(ic)::value;
-      constexpr int N = I + 1, ntap = N / 2;               // the sub-step whose A fragments are read now
+      constexpr int N = FA_SETS == 2 ? I + 1 : I, ntap = N / 2;   // the sub-step whose A fragments are read now
       if constexpr (N < 18) {
-        if constexpr (N % 6 == 0) set_row(ntap / 3);       // next tap row
-        aread(ntap % 3, N & 1, fa[N & 1]);
+        if constexpr (N % 6 == 0 && N > 0) set_row(ntap / 3);     // next tap row
+        aread(ntap % 3, N & 1, fa[N % FA_SETS]);
       }
       bload(u0 + I + 2, bq[(I + 2) % 3]);
       if constexpr (I == 2 * PATCH_PF_TAP) {
         if (cb + 1 < cend) pa.issue(cb + 1, staging);      // lands while the remaining taps run
       }
       __builtin_amdgcn_sched_barrier(0);
-      mfma24(fa[I & 1], bq[I % 3]);
+      mfma24(fa[I % FA_SETS], bq[I % 3]);
       __builtin_amdgcn_sched_barrier(0);
     };
     substep(std::integral_constant<int, 0>());
@@ -870,7 +862,7 @@ __device__ __forceinline__ void gemm_mainloop_patch_bf3(const PA& pa, const Conv
       lds_barrier();
     }
   }
-  __syncthreads();
+  lds_barrier();
 }
 
 __device__ __forceinline__ float apply_act(float v, int act, float alpha) {
@@ -946,7 +938,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         smem[((wr * WM + m) * 32 + frag_row(lane, r)) * CS + (wc * WN + n) * 32 + (lane & 31)] = acc[m][n][r];
-  __syncthreads();
+  lds_barrier();
 
   const int c4 = tid % CPR;
   const int r0 = tid / CPR;
@@ -1025,7 +1017,84 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
       }
     }
   }
-  __syncthreads();
+  lds_barrier();
+}
+
+// The common case of conv_epilogue, written lean: plain output geometry (y_ld == Cout, no view, no sub-sampling), Cout % 4 == 0,
+// unit-stride shortcut, 32-bit byte offsets (ConvArgs::epi_fast, decided on the host).  Same arithmetic, element by element.
+// Why it exists: conv_epilogue serves every layer shape through run-time flags; compiled into the persistent kernels it came
+// out as a forest of uniform branches with 64-bit address arithmetic, SGPR spills restored by v_readlane in front of every
+// store, and -- fatal -- a VGPR spill reloaded from scratch at the end of every row group: `scratch_load; s_waitcnt vmcnt(0)`
+// waits, through the in-order vmcnt, for the stores just issued to be acknowledged, 2-3 us per group of rows.  Block traces
+// (net.hip: option dbg = 256) showed 13-17 us of epilogue per 64 x 64 tile against 18 us of mainloop on the 64-channel layers.
+// Here every access is a buffer access with a 32-bit offset (out-of-range = dropped / zero replaces each predicate, a null
+// tensor gets an empty descriptor), the shortcut rows of a group are requested together, and nothing is carried but the offsets.
+template <class T, bool TILE2D>
+__device__ __forceinline__ void conv_epilogue_fast(const ConvArgs& a, f32x16 (&acc)[T::WM][T::WN], int m0, int n0,
+                                                   float* smem, const EpiRes<T>& er, bool res_loaded) {
+  constexpr int WM = T::WM, WN = T::WN;
+  constexpr int CS = T::BN + 4, CPR = T::BN / 4, RPP = T::NT / CPR, ITER = T::BM / RPP;
+  constexpr int CH = ITER < 4 ? ITER : 4;                   // rows per group
+  static_assert(ITER % CH == 0, "epilogue row groups");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wr = T::wave_row(), wc = T::wave_col();
+#pragma unroll
+  for (int m = 0; m < WM; ++m)
+#pragma unroll
+    for (int n = 0; n < WN; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        smem[((wr * WM + m) * 32 + frag_row(lane, r)) * CS + (wc * WN + n) * 32 + (lane & 31)] = acc[m][n][r];
+  lds_barrier();
+  const int c4 = tid % CPR, r0 = tid / CPR;
+  const int c = n0 + c4 * 4;
+  const bool col_ok = c < a.Cout;
+  const uint32_t bytes = (uint32_t)a.M * (uint32_t)a.Cout * 4u;
+  const __amdgpu_buffer_rsrc_t y_rsrc = make_rsrc(a.y, a.y ? bytes : 0u);
+  const __amdgpu_buffer_rsrc_t y2_rsrc = make_rsrc(a.y2, a.y2 ? bytes : 0u);
+  const __amdgpu_buffer_rsrc_t res_rsrc = make_rsrc(a.res, a.res ? bytes : 0u);
+  const int cc = col_ok ? c : 0;
+  const f32x4 sc = load4_or(a.scale, cc, 1.f), sh = load4_or(a.shift, cc, 0.f), al = load4_or(a.alpha, cc, 0.f);
+  const f32x4 sc2 = load4_or(a.scale2, cc, 1.f), sh2 = load4_or(a.shift2, cc, 0.f), al2 = load4_or(a.alpha2, cc, 0.f);
+  const int act = a.act, act2 = a.act2;
+  int t2_pix0 = 0;
+  if constexpr (TILE2D) {
+    int n, h0, w0;
+    t2_pix0 = tile2d_pix0(a, m0, n, h0, w0);
+  }
+  const bool has_res = a.res != nullptr;
+  const float* srow = smem + r0 * CS + c4 * 4;
+#pragma unroll
+  for (int i0 = 0; i0 < ITER; i0 += CH) {
+    uint32_t voff[CH];
+    f32x4 rv[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int rl = r0 + (i0 + j) * RPP;
+      const int row = TILE2D ? t2_pix0 + (rl >> 3) * a.W + (rl & 7) : m0 + rl;
+      voff[j] = (col_ok && row < a.M) ? ((uint32_t)row * (uint32_t)a.Cout + (uint32_t)c) * 4u : OOB;
+      rv[j] = res_loaded ? er.rv[i0 + j] : (has_res ? buf_load4(res_rsrc, voff[j]) : f32x4{0.f, 0.f, 0.f, 0.f});
+    }
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const f32x4 av = *reinterpret_cast<const f32x4*>(srow + (i0 + j) * RPP * CS);
+      f32x4 v, v2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = fmaf(av[e], sc[e], sh[e]);
+        const float tr = fmaxf(t, 0.f), tp = t >= 0.f ? t : t * al[e];
+        t = act == ACT_RELU ? tr : (act == ACT_PRELU ? tp : (act == ACT_RELU6 ? fminf(tr, 6.f) : t));
+        if (has_res) t += rv[j][e];
+        v[e] = t;
+        float u = fmaf(t, sc2[e], sh2[e]);
+        const float ur = fmaxf(u, 0.f), up = u >= 0.f ? u : u * al2[e];
+        v2[e] = act2 == ACT_RELU ? ur : (act2 == ACT_PRELU ? up : (act2 == ACT_RELU6 ? fminf(ur, 6.f) : u));
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), y_rsrc, voff[j], 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v2), y2_rsrc, voff[j], 0, 0);
+    }
+  }
+  lds_barrier();
 }
 
 // XCD-aware remap of the hardware block id: blocks b, b+8, b+16, ... share an XCD (and its
@@ -1235,7 +1304,10 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const 
       }
       if (a.trace) tC = __builtin_amdgcn_s_memrealtime();
       // (the split-bf16 kernel's operand rings are dead by now: it has the registers to fetch the shortcut tile at once)
-      conv_epilogue<T, !PATCH || B3P, AMP == 6, !BF3>(a, acc, m0, n0, smem, er, whole);
+      if (a.epi_fast)
+        conv_epilogue_fast<T, AMP == 6>(a, acc, m0, n0, smem, er, whole && a.res != nullptr);
+      else
+        conv_epilogue<T, !PATCH || B3P, AMP == 6, !BF3>(a, acc, m0, n0, smem, er, whole);
     }
     if (a.trace) {
       const unsigned long long tD = __builtin_amdgcn_s_memrealtime();
@@ -1409,14 +1481,14 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_pipe_kernel(const C
         if constexpr (CPS > 3) epi_post(std::integral_constant<int, J * CPS + 3>());
       }
       if (more) stage((ks & 1) ^ 1);
-      __syncthreads();
+      lds_barrier();
     };
 
     const unsigned long long tB = a.trace ? __builtin_amdgcn_s_memrealtime() : 0;
     ald.load(0, ra);
     bld.load(0, rb);
     stage(0);
-    __syncthreads();
+    lds_barrier();
     const unsigned long long tC = a.trace ? __builtin_amdgcn_s_memrealtime() : 0;
     // the first eight steps carry the previous tile's epilogue, unrolled so that its accumulator
     // registers are addressed statically
@@ -1970,6 +2042,10 @@ static int launch_conv_pre(const ConvArgs& a, hipStream_t st) {
   b.fd_t2_img = make_fastdiv((a.H / 8) * (a.W / 8) > 0 ? (a.H / 8) * (a.W / 8) : 1);
   if (a.k_order == 1 && a.Cin % BK != 0) return set_error("conv: channel-block-major K order needs Cin %% 32 == 0");
   b.fd_tiles_n = make_fastdiv((a.Cout + T::BN - 1) / T::BN);
+  // the lean epilogue's case (conv_epilogue_fast)
+  b.epi_fast = !(a.dbg & 1024) && a.y_H == a.Ho && a.y_W == a.Wo && a.y_oy == 0 && a.y_ox == 0 && a.y_ld == a.Cout && a.y_coff == 0 &&
+               !a.y_sub && a.Cout % 4 == 0 && (!a.res || (a.res_stride == 1 && a.res_H == a.Ho && a.res_W == a.Wo)) &&
+               (int64_t)a.M * a.Cout * 4 < 0xFFFFFFF0LL;
   hipLaunchKernelGGL(kern, dim3((unsigned)P), dim3(T::NT), lds_bytes, st, b);
   DIF_HIP(hipGetLastError());
   return 0;

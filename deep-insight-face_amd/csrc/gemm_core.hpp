@@ -63,6 +63,16 @@ struct Tile {
 __device__ __forceinline__ int frag_row(int lane, int reg) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 __device__ __forceinline__ int frag_col(int lane) { return lane & 31; }
 
+// LDS-only workgroup barrier: the fences name the local address space, so the compiler waits for this wave's LDS
+// operations (lgkmcnt) but leaves its global loads -- the B fragments requested ahead -- in flight across the barrier
+// (__syncthreads() drains vmcnt as well -- the B prefetch at every patch swap, and every global STORE in flight: the
+// epilogue's output tile, the pipelined kernels' retiring stores -- although all the kernels ever share is LDS)
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // Accumulates K-steps [kbeg, kend) into acc.  Ends on a barrier (LDS is free afterwards).
 // Loader concept:
 //   struct L { __device__ void load(int kstep, f32x4 (&r)[N]);    // issue the loads of one K-step
@@ -94,7 +104,7 @@ __device__ __forceinline__ void gemm_mainloop(ALoader& al, BLoader& bl, int kbeg
   for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(lds + st_off + i * RP * LDS_STRIDE) = ra[i];
 #pragma unroll
   for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(lds + OFFB + st_off + i * RP * LDS_STRIDE) = rb[i];
-  __syncthreads();
+  lds_barrier();
 
   for (int ks = kbeg; ks < kend; ++ks) {
     const int cur = (ks - kbeg) & 1;
@@ -140,7 +150,7 @@ __device__ __forceinline__ void gemm_mainloop(ALoader& al, BLoader& bl, int kbeg
 #pragma unroll
       for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(wb + i * RP * LDS_STRIDE) = rb[i];
     }
-    __syncthreads();
+    lds_barrier();
   }
 }
 
@@ -201,7 +211,7 @@ __device__ __forceinline__ void gemm_mainloop2(ALoader& al, BLoader& bl, int kbe
   al.load(kbeg, ra);
   bl.load(kbeg, rb);
   stage(0, ra, rb);
-  __syncthreads();
+  lds_barrier();
   int ks = kbeg;
   for (; ks + 1 < kend; ++ks) {
     const int cur = (ks - kbeg) & 1;
@@ -213,11 +223,11 @@ __device__ __forceinline__ void gemm_mainloop2(ALoader& al, BLoader& bl, int kbe
     __builtin_amdgcn_sched_barrier(0);
     mfma_step(cur);
     stage(cur ^ 1, ra, rb);
-    __syncthreads();
+    lds_barrier();
   }
   tail();
   mfma_step((ks - kbeg) & 1);
-  __syncthreads();
+  lds_barrier();
 }
 
 
@@ -301,7 +311,7 @@ __device__ __forceinline__ void gemm_mainloop_bf2(ALoader& al, BLoader& bl, int 
   for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(lds + st_off + i * RP * LDS_STRIDE) = ra[i];
 #pragma unroll
   for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(lds + OFFB + st_off + i * RP * LDS_STRIDE) = rb[i];
-  __syncthreads();
+  lds_barrier();
   for (int ks = kbeg; ks < kend; ++ks) {
     const int cur = (ks - kbeg) & 1;
     const bool more = ks + 1 < kend;
@@ -346,7 +356,7 @@ __device__ __forceinline__ void gemm_mainloop_bf2(ALoader& al, BLoader& bl, int 
 #pragma unroll
       for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(wb + i * RP * LDS_STRIDE) = rb[i];
     }
-    __syncthreads();
+    lds_barrier();
   }
 }
 
@@ -408,7 +418,7 @@ __device__ __forceinline__ void gemm_mainloop_dma(ALoader& al, BLoader& bl, int 
   al.issue(kbeg, lds);
   bl.issue(kbeg, lds + OFFB);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  lds_barrier();
   for (int ks = kbeg; ks < kend; ++ks) {
     const int cur = (ks - kbeg) & 1;
     if (ks + 1 < kend) {
@@ -442,7 +452,7 @@ __device__ __forceinline__ void gemm_mainloop_dma(ALoader& al, BLoader& bl, int 
                                                              acc[m][n], 0, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMAs of step ks+1 have landed
-    __syncthreads();                                    // ... and everybody else's
+    lds_barrier();                                    // ... and everybody else's
   }
 }
 

@@ -91,6 +91,7 @@ struct ConvArgs {
                         // launches are short and the lanes run half-chip grids: measured 1-2 % slower there; Net option
                         // "bdp" = 0), 2 wherever its restrictions allow (Net option "bdp" = 2: the parity tests)
   int use_pipe;         // 0: never take the software-pipelined kernel (Net option "pipe"; tests compare both paths)
+  int epi_fast;         // the output takes conv.hip's lean epilogue (plain geometry, 32-bit offsets); filled by conv_run
   int dbg;              // development aid (ablation bits of the kernel under work); 0 in production
   unsigned off;         // kernel families switched off (Net options "patch", "patch2d", "bd" = 0): CONV_OFF_* bits
   // development aid (tools/ubench/conv_trace.hip), null in the library: 4 x u64 per hardware block =

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libdif.so')
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', os.environ.get('DIF_LIB', 'libdif.so'))   # DIF_LIB: same-box A/B of two builds
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
