@@ -175,3 +175,42 @@ def test_odd_sizes_pipelined_vs_plain_vs_oracle(cuda, monkeypatch, arch, head, e
         want = nets.embed(scaled(x[rows].cpu().numpy()), m.get_weights(), arch, emd, head)
         assert cosine_gap(a[rows].cpu().numpy(), want).max() < TOL
     m.close()
+
+
+@pytest.mark.parametrize('batch', [256, 512])
+def test_iresnet100_full_batch_bf16x3(r100, batch):
+    """The split-bf16 throughput mode (conv.hip: gemm_mainloop_patch_bf3, the B-direct halo-patch kernel on 128 x 128 tiles
+    with the stream-K grid cut at slice boundaries) at the benchmarked sizes and under the default executor: against the
+    float32 path of the same weights on the whole batch (cosine gap < 1e-6), against the oracle on spot rows of both lanes
+    (gap < 1e-5, pairwise cosine distances within 1e-5), finite, unit norm, deterministic, and on a gallery built from the
+    float32 embeddings every split-bf16 probe names its own row."""
+    from deep_insight_face import oneshot
+    from deep_insight_face.networks.triplet import DifEmbedder
+    model, p = r100
+    b3 = DifEmbedder('iresnet100', 'v2', 512, (112, 112, 3), max_batch=512, compute='bf16x3')
+    b3.set_weights(p)
+    b3.set_input_transform(scale=1 / 255.)
+    u8 = crops_u8(batch, seed=5200 + batch)
+    dev = torch.from_numpy(u8).cuda()
+    ref = model.embed(dev)
+    got = b3.embed(dev)
+    assert torch.equal(got, b3.embed(dev))
+    assert not torch.equal(got, ref)                                # really another arithmetic
+    g, r = got.cpu().numpy(), ref.cpu().numpy()
+    assert np.all(np.isfinite(g))
+    np.testing.assert_allclose(np.linalg.norm(g, axis=1), 1.0, atol=1e-5)
+    assert cosine_gap(g, r).max() < 1e-6
+    half = batch // 2
+    rows = [0, half - 1, half, batch - 1]
+    want = nets.embed(scaled(u8[rows]), p, 'iresnet100', 512, 'v2')
+    assert cosine_gap(g[rows], want).max() < TOL
+    for i in range(len(rows)):
+        a = od.distance(np.repeat(g[rows][i][None], len(rows), 0), g[rows], 1)
+        b = od.distance(np.repeat(want[i][None], len(rows), 0), want, 1)
+        mask = np.arange(len(rows)) != i
+        np.testing.assert_allclose(a[mask], b[mask], atol=TOL)
+    gal = oneshot.Gallery(ref)
+    idx, _ = gal.match(got, 1)
+    assert torch.equal(idx.cpu(), torch.arange(batch))
+    gal.close()
+    b3.close()
