@@ -659,10 +659,10 @@ __device__ __forceinline__ void gemm_mainloop_patch_bd(const PA& pa, const ConvA
 // Per wave and K-step: 48 MFMAs (1536 matrix-pipe cycles) against 12 ds_read_b128 and 12 coalesced 1 KB loads.
 constexpr int BF3P_EB = 208;          // bytes per patch entry
 constexpr int BF3P_KSTEP_B = 6144;    // bytes of w3f per (32-column tile, K-step)
-constexpr int PATCH_EMAX_B3 = 232;    // entries a 128-pixel linear tile can need on maps up to 28 wide (host-checked bound)
-constexpr int BF3P_PLANES_B = PATCH_EMAX_B3 * BF3P_EB;            // the split patch ...
-constexpr int BF3P_STAGE_B = PATCH_EMAX_B3 * 128;                 // ... and, behind it, the next slice's f32 patch as it arrives
-constexpr int BF3P_LDS_B = BF3P_PLANES_B + BF3P_STAGE_B;
+// entries a BM-pixel linear tile can need on maps 7 .. 28 wide (host-checked bound): 232 for 128 pixels, 408 for 256
+constexpr int bf3p_emax(int bm) { return bm == 128 ? 232 : 408; }
+constexpr int bf3p_planes_b(int bm) { return bf3p_emax(bm) * BF3P_EB; }      // the split patch ...
+constexpr int bf3p_lds_b(int bm) { return bf3p_emax(bm) * (BF3P_EB + 128); } // ... and, behind it, the next slice's f32 patch as it arrives
 
 // The f32 patch of one 32-channel slice, fetched global -> LDS by LDS-DMA (buffer_load ... lds: no staging registers --
 // held in registers across the five taps it is in flight the prefetch cost 32 VGPRs, and every scratch reload of a spilled
@@ -759,10 +759,10 @@ template <class T, class PA>
 __device__ __forceinline__ void gemm_mainloop_patch_bf3(const PA& pa, const ConvArgs& a, int n0, int cbeg, int cend,
                                                         char* lds, f32x16 (&acc)[T::WM][T::WN]) {
   constexpr int WM = T::WM, WN = T::WN;
-  static_assert(WM * WN == 4 && T::NT == 256, "split-bf16 patch path: four waves, four accumulator fragments each");
+  static_assert(WM * WN == 4, "split-bf16 patch path: four accumulator fragments per wave");
   const int lane = threadIdx.x & 63, h = lane >> 5;
   const int KS = a.Kpad / BK;
-  char* staging = lds + BF3P_PLANES_B;
+  char* staging = lds + bf3p_planes_b(T::BM);
   const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.w3f, a.w3f_bytes);
   uint32_t boff[WN];
 #pragma unroll
@@ -806,14 +806,25 @@ __device__ __forceinline__ void gemm_mainloop_patch_bf3(const PA& pa, const Conv
     for (int m = 0; m < WM; ++m) arow[m] = (uint32_t)(pa.base[m] + kh * pa.WP) * (uint32_t)BF3P_EB + (uint32_t)h * 16u;
   };
 
-  constexpr int FA_SETS = 2;     // A fragment sets: 2 = read one sub-step ahead, 1 = read right before their MFMAs
-  u32x4 bq[3][WN][3];
+  // B fragments: a ring of RING sub-step sets requested RING - 1 sub-steps ahead (18 % RING == 0 keeps the ring's phase fixed
+  // per slice); A fragments: FA_SETS sets (2 = read one sub-step ahead, 1 = right before their MFMAs).
+  // What the loop is bound by (profiles/r03_ablation.txt): with real operands a K-step takes 2.0-2.1 us against 1.34 us of
+  // matrix-pipe time, and NOTHING about the operand streams moves it -- half the B bytes per MFMA (256-row blocks), half the B
+  // loads per wave (128 x 32 wave tiles), a ring of six sets (2.5 K-steps ahead), accumulators in AccVGPRs.  With all-zero
+  // WEIGHTS -- same instructions, same loads, same bytes -- it runs 20 % faster and the clock held inside the kernels goes from
+  // 2.06 to 2.38 GHz: six bf16 MFMAs per product on random data are limited by board power, not by this loop's structure.
+  constexpr int RING = WN == 1 ? 6 : 3, LOOK = RING - 1;
+  constexpr int FA_SETS = WN == 1 ? 1 : 2;
+  static_assert(18 % RING == 0, "ring phase");
+  u32x4 bq[RING][WN][3];
   u32x4 fa[FA_SETS][WM][3];
   pa.issue(cbeg, staging);
-  bload(18 * cbeg, bq[0]);
-  bload(18 * cbeg + 1, bq[1]);
-  if constexpr (WN == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // the patch has landed (the B loads behind it may be in flight)
-  else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < LOOK; ++i) bload(18 * cbeg + i, bq[i]);
+  // the patch has landed (the LOOK * 3 * WN B loads behind it may be in flight)
+  if constexpr (LOOK * 3 * WN == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if constexpr (LOOK * 3 * WN == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   pa.convert(staging, lds);
   lds_barrier();
   for (int cb = cbeg; cb < cend; ++cb) {
@@ -828,12 +839,12 @@ __device__ __forceinline__ void gemm_mainloop_patch_bf3(const PA& pa, const Conv
         if constexpr (N % 6 == 0 && N > 0) set_row(ntap / 3);     // next tap row
         aread(ntap % 3, N & 1, fa[N % FA_SETS]);
       }
-      bload(u0 + I + 2, bq[(I + 2) % 3]);
+      bload(u0 + I + LOOK, bq[(I + LOOK) % RING]);
       if constexpr (I == 2 * PATCH_PF_TAP) {
         if (cb + 1 < cend) pa.issue(cb + 1, staging);      // lands while the remaining taps run
       }
       __builtin_amdgcn_sched_barrier(0);
-      mfma24(fa[I % FA_SETS], bq[I % 3]);
+      mfma24(fa[I % FA_SETS], bq[I % RING]);
       __builtin_amdgcn_sched_barrier(0);
     };
     substep(std::integral_constant<int, 0>());
@@ -855,8 +866,10 @@ __device__ __forceinline__ void gemm_mainloop_patch_bf3(const PA& pa, const Conv
     substep(std::integral_constant<int, 16>());
     substep(std::integral_constant<int, 17>());
     if (cb + 1 < cend) {
-      if constexpr (WN == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // this thread's share of the next patch is in LDS
-      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      // this thread's share of the next patch is in LDS (everything but the ring's youngest loads has landed)
+      if constexpr (LOOK * 3 * WN == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else if constexpr (LOOK * 3 * WN == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       lds_barrier();                                       // every wave has read its last fragment of the old patch
       pa.convert(staging, lds);
       lds_barrier();
@@ -927,7 +940,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
   constexpr int CPR = T::BN / 4;                // float4 chunks per tile row
   constexpr int RPP = T::NT / CPR;              // rows per pass
   constexpr int ITER = T::BM / RPP;
-  static_assert(T::BM * CS <= T::LDS_FLOATS, "accumulator tile must fit in the staging LDS");
+  static_assert(T::BM * CS <= T::LDS_FLOATS || T::BM > 128, "accumulator tile must fit in the staging LDS (the 256-row split-bf16 tile sizes its LDS itself)");
   static_assert(T::NT % CPR == 0 && T::BM % RPP == 0, "epilogue mapping");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wr = T::wave_row(), wc = T::wave_col();
@@ -1110,7 +1123,7 @@ struct NoLoader {};   // B operand of the B-direct kernels: fetched by the mainl
 // 2 multi-tap with Cin % 32 == 0 and channel-block-major K
 // BF3 (with AM = 13): the split-bf16 patch kernel, gemm_mainloop_patch_bf3 on the fragment-order split weights a.w3f
 template <class T, bool PRE, bool DMA, int AM, bool BF3 = false>
-__global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(T::NT, (BF3 ? 2 : T::MIN_BLOCKS)) void conv_igemm_kernel(const ConvArgs a) {
   static_assert(!(PRE && DMA), "pre-activation needs register staging");
   static_assert(!(AM != 0 && DMA), "the specialised loaders are register-staged");
   static_assert(!BF3 || (AM == 13 && !PRE && !DMA), "split-bf16 exists as the B-direct patch kernel only");
@@ -1119,7 +1132,7 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const 
   static_assert(!BD || PATCH, "B-direct exists for the patch paths only");
   constexpr bool B3P = BF3 && PATCH;                         // split-bf16 patch kernel: gemm_mainloop_patch_bf3
   static_assert(!PATCH || (!PRE && !DMA), "patch path: no pre-activation, register staging");
-  static_assert(!PATCH || (B3P ? (BD && T::BM == 128 && T::BN == 128 && AMP == 3) : (T::BM == 64 && T::BN == 64)), "patch path tiles");
+  static_assert(!PATCH || (B3P ? (BD && T::BN == 128 && AMP == 3) : (T::BM == 64 && T::BN == 64)), "patch path tiles");
   constexpr int WM = T::WM, WN = T::WN;
   constexpr int SLAB = T::BM * T::BN;    // floats per partial-accumulator slab
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1171,7 +1184,7 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_igemm_kernel(const 
     using ALoadReg = typename std::conditional<AM == 1, ConvPwLoader<T::NA, T::RP, PRE>,
                                                ConvALoader<T::NA, T::RP, PRE, AM == 2 ? 2 : 0>>::type;
     using ALoadGather = typename std::conditional<DMA, ConvADmaLoader<T::NA, T::RP>, ALoadReg>::type;
-    using ALoadLin = typename std::conditional<AMP == 3, typename std::conditional<B3P, PatchDma<T, PATCH_EMAX_B3>, PatchA<T, PATCH_EMAX_S>>::type,   // AM 3 / 5 / 6: halo-resident patch
+    using ALoadLin = typename std::conditional<AMP == 3, typename std::conditional<B3P, PatchDma<T, bf3p_emax(T::BM)>, PatchA<T, PATCH_EMAX_S>>::type,   // AM 3 / 5 / 6: halo-resident patch
                                                typename std::conditional<AMP == 5, PatchA<T, PATCH_EMAX_L>, ALoadGather>::type>::type;
     using ALoad = typename std::conditional<AMP == 6, PatchA2D<T>, ALoadLin>::type;
     using BLoadF32 = typename std::conditional<DMA, DmaRowLoader<T::NB, T::RP>, RowLoader<T::NB, T::RP>>::type;
@@ -1807,7 +1820,7 @@ static int allow_dynamic_lds(const void* kern, int bytes) {
 }
 
 int conv_max_blocks() { return 4 * num_cus(); }
-size_t conv_slab_floats() { return 128 * 128; }   // per resident slot: published partial + fallback stash, either tile
+size_t conv_slab_floats() { return 256 * 128; }   // per resident slot: published partial + fallback stash, either tile
                                                    // (1024 x 2 x 64x64 or 512 x 2 x 128x128 floats in all)
 
 template <class T, bool PRE, bool DMA, int AM, bool BF3 = false>
@@ -1912,7 +1925,7 @@ static int patch_applies(const ConvArgs& a) {
 static bool bf3p_applies(const ConvArgs& a) {
   if (!a.w3f || !patch_shape(a) || a.y_sub || a.Cout < 128) return false;
   if (!(a.y_H == a.Ho && a.y_W == a.Wo && a.y_oy == 0 && a.y_ox == 0)) return false;
-  return patch_entry_bound(a, 128) <= PATCH_EMAX_B3;
+  return patch_entry_bound(a, 128) <= bf3p_emax(128);
 }
 
 // the 8x8-tile form of the patch path (AM = 6): the same layers on maps whose sides are multiples of 8, where the
@@ -2005,7 +2018,7 @@ static int launch_conv_pre(const ConvArgs& a, hipStream_t st) {
   constexpr int epi_bytes = T::BM * (T::BN + 4) * 4;       // the epilogue's staging tile
   // B-direct: the patch alone (or the epilogue's staging tile if that is larger)
   constexpr int bd_bytes = emax * 128 > epi_bytes ? emax * 128 : epi_bytes;
-  constexpr int b3p_bytes = BF3P_LDS_B > epi_bytes ? BF3P_LDS_B : epi_bytes;
+  constexpr int b3p_bytes = bf3p_lds_b(T::BM) > epi_bytes ? bf3p_lds_b(T::BM) : epi_bytes;
   constexpr int lds_bytes = BF3 ? b3p_bytes
                                 : (AM >= 10 ? bd_bytes : ((AMP == 3 || AMP == 5 || AMP == 6) ? patch_lds_bytes(emax) : T::LDS_BYTES));
   if (allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds_bytes)) return -1;
@@ -2014,7 +2027,7 @@ static int launch_conv_pre(const ConvArgs& a, hipStream_t st) {
   const int64_t I = tiles * KS;
   if (I >= 0x7fffffffLL) return set_error("conv: iteration space too large");
   // Resident blocks for this tile shape (LDS-limited: 2 per CU, 4 for the 64x64 tile).
-  int64_t slots = (BF3 ? 2 : T::BLOCKS_PER_CU) * (int64_t)num_cus();
+  int64_t slots = (BF3 ? 512 / T::NT : T::BLOCKS_PER_CU) * (int64_t)num_cus();     // split-bf16: eight waves per CU
   if (slots > a.sk_max_blocks) slots = a.sk_max_blocks;
   // Many tiles, or a short K loop (< 32 steps: a split tile's slab hand-off would cost more
   // than the imbalance it removes -- measured): one whole tile per block, the hardware
@@ -2076,7 +2089,8 @@ int conv_run(const ConvArgs& a, hipStream_t st) {
     if (span * a.H * a.W * a.Cin * 4 >= 0x7fffffffLL)
       return set_error("conv: a 256-pixel tile spans more than 2 GiB of input (%dx%dx%d)", a.H, a.W, a.Cin);
   }
-  // (four waves of 128 x 32 instead -- half the B loads, twice the A reads -- measured the same: 178 vs 183 TFLOP/s)
+  // (four waves of 128 x 32 with a six-set B ring, and eight waves on a 256 x 128 tile -- Tile<4, 1, 1, 4>, Tile<2, 2, 4, 2>: the
+  // mainloop takes either -- measured the same as this one within 2 %)
   if (bf3p_applies(a)) return launch_conv_pre<Tile<2, 2, 2, 2>, false, false, 13, true>(a, st);
   return launch_conv<Tile<1, 1>>(a, st);
 }
