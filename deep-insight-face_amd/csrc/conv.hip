@@ -225,88 +225,6 @@ struct ConvPwLoader {
   }
 };
 
-// LDS-DMA flavour of the gather (no pre-activation: the data never passes through registers).
-template <int N, int RP>
-struct ConvADmaLoader {
-  __amdgpu_buffer_rsrc_t rsrc;
-  int32_t base[N];
-  int32_t hw0[N];
-  int H, W, Cin, KW, taps;
-  FastDiv fd_cin, fd_kw, fd_taps;
-  int k_order, chunk;   // chunk = the global 16-byte chunk this thread's LDS slot receives
-  bool fast;
-
-  __device__ __forceinline__ ConvADmaLoader(const ConvArgs& a, int m0) {
-    const int tid = threadIdx.x;
-    H = a.H;
-    W = a.W;
-    Cin = a.Cin;
-    KW = a.KW;
-    taps = a.KH * a.KW;
-    fast = (a.Cin % BK) == 0;
-    fd_cin = a.fd_cin;
-    fd_kw = a.fd_kw;
-    fd_taps = a.fd_taps;
-    k_order = a.k_order;
-    chunk = (tid & 7) ^ dma_swizzle(tid >> 3);
-    const int HoWo = a.Ho * a.Wo;
-    const int n_first = a.fd_howo.div(m0);
-    const int64_t img_elems = (int64_t)a.H * a.W * a.Cin;
-    const int64_t imgs_left = a.N - n_first;
-    int64_t span = (256 + HoWo - 1) / HoWo + 1;
-    if (span > imgs_left) span = imgs_left;
-    rsrc = make_rsrc(a.x + n_first * img_elems, (uint32_t)(span * img_elems * 4));
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      const int m = m0 + (tid >> 3) + RP * i;
-      if (m < a.M) {
-        int n, r, ho, wo;
-        a.fd_howo.divmod(m, n, r);
-        a.fd_wo.divmod(r, ho, wo);
-        const int hi0 = ho * a.stride - a.pad_t;
-        const int wi0 = wo * a.stride - a.pad_l;
-        base[i] = (int32_t)((((int64_t)(n - n_first) * a.H + hi0) * a.W + wi0) * a.Cin * 4) + chunk * 16;
-        hw0[i] = ((hi0 + 0x4000) << 16) | (wi0 + 0x4000);
-      } else {
-        base[i] = 0;
-        hw0[i] = 0;
-      }
-    }
-  }
-
-  __device__ __forceinline__ void issue(int kstep, float* lds_tile) const {
-    int kh, kw, toff;
-    bool tap_ok = true;
-    if (fast) {
-      int tap, ci0;
-      if (k_order == 1) {
-        int cblk;
-        fd_taps.divmod(kstep, cblk, tap);
-        ci0 = cblk * BK;
-      } else {
-        fd_cin.divmod(kstep * BK, tap, ci0);
-      }
-      fd_kw.divmod(tap, kh, kw);
-      toff = ((kh * W + kw) * Cin + ci0) * 4;
-    } else {
-      int tap, ci;
-      fd_cin.divmod(kstep * BK + chunk * 4, tap, ci);
-      fd_kw.divmod(tap, kh, kw);
-      tap_ok = tap < taps;
-      toff = ((kh * W + kw) * Cin + ci) * 4 - chunk * 16;
-    }
-    const int wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      const int hi = (hw0[i] >> 16) - 0x4000 + kh;
-      const int wi = (hw0[i] & 0xffff) - 0x4000 + kw;
-      const bool ok = tap_ok && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
-      const uint32_t off = ok ? (uint32_t)(base[i] + toff) : OOB;
-      dma_load16(rsrc, lds_tile + (wave * 8 + RP * i) * BK, off);
-    }
-  }
-};
-
 // ------------------------------------------------------------------------------------------
 // Halo-resident A operand for 3x3 / stride 1 / pad 1 layers ("patch" path, AM = 3).
 //
@@ -1122,16 +1040,14 @@ struct NoLoader {};   // B operand of the B-direct kernels: fetched by the mainl
 // AM (A-operand gather mode): 0 general, 1 pointwise (1x1, no padding, Cin % 32 == 0),
 // 2 multi-tap with Cin % 32 == 0 and channel-block-major K
 // BF3 (with AM = 13): the split-bf16 patch kernel, gemm_mainloop_patch_bf3 on the fragment-order split weights a.w3f
-template <class T, bool PRE, bool DMA, int AM, bool BF3 = false>
+template <class T, bool PRE, int AM, bool BF3 = false>
 __global__ __launch_bounds__(T::NT, (BF3 ? 2 : T::MIN_BLOCKS)) void conv_igemm_kernel(const ConvArgs a) {
-  static_assert(!(PRE && DMA), "pre-activation needs register staging");
-  static_assert(!(AM != 0 && DMA), "the specialised loaders are register-staged");
-  static_assert(!BF3 || (AM == 13 && !PRE && !DMA), "split-bf16 exists as the B-direct patch kernel only");
+  static_assert(!BF3 || (AM == 13 && !PRE), "split-bf16 exists as the B-direct patch kernel only");
   constexpr int AMP = AM % 10;                              // AM >= 10: the B-direct form of patch path AM - 10
   constexpr bool PATCH = (AMP == 3 || AMP == 5 || AMP == 6), BD = AM >= 10;
   static_assert(!BD || PATCH, "B-direct exists for the patch paths only");
   constexpr bool B3P = BF3 && PATCH;                         // split-bf16 patch kernel: gemm_mainloop_patch_bf3
-  static_assert(!PATCH || (!PRE && !DMA), "patch path: no pre-activation, register staging");
+  static_assert(!PATCH || !PRE, "patch path: no pre-activation");
   static_assert(!PATCH || (B3P ? (BD && T::BN == 128 && AMP == 3) : (T::BM == 64 && T::BN == 64)), "patch path tiles");
   constexpr int WM = T::WM, WN = T::WN;
   constexpr int SLAB = T::BM * T::BN;    // floats per partial-accumulator slab
@@ -1145,23 +1061,9 @@ __global__ __launch_bounds__(T::NT, (BF3 ? 2 : T::MIN_BLOCKS)) void conv_igemm_k
   const int tiles_n = (a.Cout + T::BN - 1) / T::BN;
   const int tiles_m = (a.M + T::BM - 1) / T::BM;
   const int I = tiles_m * tiles_n * KS;                       // < 2^31 (checked by conv_run)
-  // Start of (remapped) block q's share of the iteration space.  With the chip full (P = 4 blocks on every
-  // CU) the four co-resident blocks do NOT advance at the same rate: the wave arbiter favours older waves,
-  // so the block dispatched first to a CU finishes an equal share ~20 % earlier than the one dispatched
-  // last (477 / 512 / 554 / 583 us measured on a 595 us launch) and the CU idles while the late ones
-  // finish.  Shares are therefore weighted by the resident slot, w = 1 + skew * (1.5 - slot): in remapped
-  // order an XCD's 128 blocks are four runs of 32 (slot 0..3), so the prefix sum is piecewise linear.
-  // skew_q16 = 0 gives the equal split; the split stays a pure function of the problem (deterministic).
-  const int skew = a.sk_skew_q16;
-  auto sk_begin = [&](int q) -> int {
-    if (skew == 0 || q >= P) return (int)((int64_t)I * q / P);
-    const int j = q & 127, g = j >> 5, r = j & 31;
-    // 65536 * (32 * sum_{s<g} w_s + r * w_g), with w_s = 1 + skew * (1.5 - s)
-    const int64_t wsum = (int64_t)g * 32 * 65536 + (int64_t)skew * 16 * (3 * g - g * (g - 1));
-    const int64_t wg = 65536 + (int64_t)skew * (3 - 2 * g) / 2;
-    const int64_t W = (int64_t)(q - j) * 65536 + wsum + r * wg;      // q - j = whole XCD runs before this one
-    return (int)(((int64_t)I * W) / ((int64_t)P * 65536));      // I < 2^31, W <= 2^26
-  };
+  // Start of (remapped) block q's share of the iteration space: equal shares (weighting them by the resident slot -- the
+  // four co-resident blocks of a CU do not advance at the same rate -- measured no gain); a pure function of the problem.
+  auto sk_begin = [&](int q) -> int { return (int)((int64_t)I * q / P); };
   const int beg = sk_begin(p), end = sk_begin(p + 1);
 
   // development aid: time per phase, summed over the block's tiles (100 MHz ticks)
@@ -1180,14 +1082,13 @@ __global__ __launch_bounds__(T::NT, (BF3 ? 2 : T::MIN_BLOCKS)) void conv_igemm_k
 
     f32x16 acc[WM][WN];
     zero_acc<T>(acc);
-    // pre-activation needs the operand in registers; everything else streams through LDS-DMA
     using ALoadReg = typename std::conditional<AM == 1, ConvPwLoader<T::NA, T::RP, PRE>,
                                                ConvALoader<T::NA, T::RP, PRE, AM == 2 ? 2 : 0>>::type;
-    using ALoadGather = typename std::conditional<DMA, ConvADmaLoader<T::NA, T::RP>, ALoadReg>::type;
+    using ALoadGather = ALoadReg;
     using ALoadLin = typename std::conditional<AMP == 3, typename std::conditional<B3P, PatchDma<T, bf3p_emax(T::BM)>, PatchA<T, PATCH_EMAX_S>>::type,   // AM 3 / 5 / 6: halo-resident patch
                                                typename std::conditional<AMP == 5, PatchA<T, PATCH_EMAX_L>, ALoadGather>::type>::type;
     using ALoad = typename std::conditional<AMP == 6, PatchA2D<T>, ALoadLin>::type;
-    using BLoadF32 = typename std::conditional<DMA, DmaRowLoader<T::NB, T::RP>, RowLoader<T::NB, T::RP>>::type;
+    using BLoadF32 = RowLoader<T::NB, T::RP>;
     using BLoad = typename std::conditional<B3P, NoLoader, BLoadF32>::type;
     ALoad al(a, m0);
     BLoad bl = [&] {
@@ -1198,7 +1099,7 @@ __global__ __launch_bounds__(T::NT, (BF3 ? 2 : T::MIN_BLOCKS)) void conv_igemm_k
     }();
     // this block computes the whole tile: fetch the shortcut tile behind the last K-step
     // (not on the patch path: its prefetch registers leave no room, the shortcut tile would only be spilled)
-    const bool whole = !DMA && !PATCH && kb == 0 && ke == KS;
+    const bool whole = !PATCH && kb == 0 && ke == KS;
     EpiRes<T> er;
     auto run = [&](int k0, int k1, bool prefetch_res) {
       if constexpr (B3P)
@@ -1211,8 +1112,6 @@ __global__ __launch_bounds__(T::NT, (BF3 ? 2 : T::MIN_BLOCKS)) void conv_igemm_k
         gemm_mainloop_patch<T>(al, bl, k0, k1, smem, acc, [&] {
           if (prefetch_res && a.res) er.load(a, m0, n0);
         });
-      else if constexpr (DMA)
-        gemm_mainloop_dma<T>(al, bl, k0, k1, smem, acc);
       else
         gemm_mainloop2<T>(al, bl, k0, k1, smem, acc, [&] {
           if (prefetch_res && a.res) er.load(a, m0, n0);
@@ -1823,7 +1722,7 @@ int conv_max_blocks() { return 4 * num_cus(); }
 size_t conv_slab_floats() { return 256 * 128; }   // per resident slot: published partial + fallback stash, either tile
                                                    // (1024 x 2 x 64x64 or 512 x 2 x 128x128 floats in all)
 
-template <class T, bool PRE, bool DMA, int AM, bool BF3 = false>
+template <class T, bool PRE, int AM, bool BF3 = false>
 static int launch_conv_pre(const ConvArgs& a, hipStream_t st);
 
 // Short K loop, several whole tiles per resident block, plain output, unit-stride shortcut: the
@@ -1885,7 +1784,6 @@ static int launch_conv_bdp(const ConvArgs& a, hipStream_t st) {
   if (P > (I + 3) / 4) P = (I + 3) / 4;
   if (P < 1) P = 1;
   ConvArgs b = a;
-  b.sk_skew_q16 = 0;
   b.fd_howo = make_fastdiv(a.Ho * a.Wo);
   b.fd_wo = make_fastdiv(a.Wo);
   b.fd_cin = make_fastdiv(a.Cin);
@@ -1972,7 +1870,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
     const bool bd = !(a.off & CONV_OFF_BD) && a.w_frag != nullptr;
     if (patch2d_applies(a)) {
       if (bd && conv_bdp_ok(a)) return launch_conv_bdp<T, 6>(a, st);
-      return bd ? launch_conv_pre<T, false, false, 16>(a, st) : launch_conv_pre<T, false, false, 6>(a, st);
+      return bd ? launch_conv_pre<T, false, 16>(a, st) : launch_conv_pre<T, false, 6>(a, st);
     }
     // the deferred-epilogue patch kernel before the pipelined (gather) one: with very many tiles (batch 512 on one lane)
     // the 128-channel 28x28 layers qualify for both
@@ -1990,8 +1888,8 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
       if (!a.pre_scale) return launch_conv_pipe<T, false, 0, 1>(a, st);
     }
   }
-  if (pw && a.pre_scale) return launch_conv_pre<T, true, false, 1>(a, st);
-  if (pw) return launch_conv_pre<T, false, false, 1>(a, st);
+  if (pw && a.pre_scale) return launch_conv_pre<T, true, 1>(a, st);
+  if (pw) return launch_conv_pre<T, false, 1>(a, st);
   if constexpr (kDefaultTile) {
     {
       const bool bd2 = !(a.off & CONV_OFF_BD) && a.w_frag != nullptr;
@@ -2001,18 +1899,18 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
         if (emax == PATCH_EMAX_L) return launch_conv_bdp<T, 5>(a, st);
         if (patch2d_applies(a)) return launch_conv_bdp<T, 6>(a, st);
       }
-      if (emax == PATCH_EMAX_S) return bd2 ? launch_conv_pre<T, false, false, 13>(a, st) : launch_conv_pre<T, false, false, 3>(a, st);
-      if (emax == PATCH_EMAX_L) return bd2 ? launch_conv_pre<T, false, false, 15>(a, st) : launch_conv_pre<T, false, false, 5>(a, st);
-      if (patch2d_applies(a)) return bd2 ? launch_conv_pre<T, false, false, 16>(a, st) : launch_conv_pre<T, false, false, 6>(a, st);
+      if (emax == PATCH_EMAX_S) return bd2 ? launch_conv_pre<T, false, 13>(a, st) : launch_conv_pre<T, false, 3>(a, st);
+      if (emax == PATCH_EMAX_L) return bd2 ? launch_conv_pre<T, false, 15>(a, st) : launch_conv_pre<T, false, 5>(a, st);
+      if (patch2d_applies(a)) return bd2 ? launch_conv_pre<T, false, 16>(a, st) : launch_conv_pre<T, false, 6>(a, st);
     }
   }
-  if (a.pre_scale) return launch_conv_pre<T, true, false, 0>(a, st);
-  return launch_conv_pre<T, false, false, 0>(a, st);
+  if (a.pre_scale) return launch_conv_pre<T, true, 0>(a, st);
+  return launch_conv_pre<T, false, 0>(a, st);
 }
 
-template <class T, bool PRE, bool DMA, int AM, bool BF3>
+template <class T, bool PRE, int AM, bool BF3>
 static int launch_conv_pre(const ConvArgs& a, hipStream_t st) {
-  auto kern = conv_igemm_kernel<T, PRE, DMA, AM, BF3>;
+  auto kern = conv_igemm_kernel<T, PRE, AM, BF3>;
   constexpr int AMP = AM % 10;
   constexpr int emax = AMP == 3 ? PATCH_EMAX_S : (AMP == 5 ? PATCH_EMAX_L : 100);
   constexpr int epi_bytes = T::BM * (T::BN + 4) * 4;       // the epilogue's staging tile
@@ -2042,7 +1940,6 @@ static int launch_conv_pre(const ConvArgs& a, hipStream_t st) {
   }
   if (P < 1) P = 1;
   ConvArgs b = a;
-  b.sk_skew_q16 = 0;   // slot-weighted stream-K shares (sk_begin) measured no gain: equal shares
   b.fd_howo = make_fastdiv(a.Ho * a.Wo);
   b.fd_wo = make_fastdiv(a.Wo);
   b.fd_cin = make_fastdiv(a.Cin);
@@ -2091,7 +1988,7 @@ int conv_run(const ConvArgs& a, hipStream_t st) {
   }
   // (four waves of 128 x 32 with a six-set B ring, and eight waves on a 256 x 128 tile -- Tile<4, 1, 1, 4>, Tile<2, 2, 4, 2>: the
   // mainloop takes either -- measured the same as this one within 2 %)
-  if (bf3p_applies(a)) return launch_conv_pre<Tile<2, 2, 2, 2>, false, false, 13, true>(a, st);
+  if (bf3p_applies(a)) return launch_conv_pre<Tile<2, 2, 2, 2>, false, 13, true>(a, st);
   return launch_conv<Tile<1, 1>>(a, st);
 }
 

@@ -384,97 +384,6 @@ struct RowLoader {
   }
 };
 
-// ------------------------------------------------------------------------------------------
-// LDS-DMA variant of the mainloop: operand tiles go global -> LDS directly
-// (buffer_load_dwordx4 ... lds: no staging VGPRs, no ds_write pass).  One wave instruction
-// writes 1 KiB of LDS lane-linearly (wave-uniform base + lane*16), i.e. 8 rows of 128 B, so the
-// LDS image is UNPADDED [row][32 floats]; bank conflicts of the fragment reads are removed by
-// an XOR swizzle of the 16-byte chunk index, chunk' = chunk ^ ((row >> 1) & 7), applied on the
-// SOURCE side (each lane fetches the global chunk that belongs in its fixed LDS slot) and on
-// the fragment-read address (cdna_hip_programming.md rule 21).  Out-of-range lanes write
-// zeros to LDS (probed on gfx950: tools/ubench/lds_dma_probe), so halos and tails still need no
-// branches.  Measured +1..5 % over register staging (tools/ubench/gemm_bench3.hip), at ~25 %
-// fewer VGPRs.
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
-__device__ __forceinline__ int dma_swizzle(int row) { return (row >> 1) & 7; }
-
-__device__ __forceinline__ void dma_load16(__amdgpu_buffer_rsrc_t rsrc, float* lds_dst, uint32_t byte_off) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds_dst, 16, byte_off, 0, 0, 0);
-}
-
-// DMA loader concept:  struct L { __device__ void issue(int kstep, float* lds_tile); };
-// Thread t owns LDS slot (row (t>>3) + RP*i, chunk t&7) of the tile image.
-template <class T, class ALoader, class BLoader>
-__device__ __forceinline__ void gemm_mainloop_dma(ALoader& al, BLoader& bl, int kbeg, int kend, float* lds,
-                                                  f32x16 (&acc)[T::WM][T::WN]) {
-  constexpr int WM = T::WM, WN = T::WN, BM = T::BM, BN = T::BN;
-  constexpr int BUF = (BM + BN) * BK, OFFB = BM * BK;
-  const int lane = threadIdx.x & 63;
-  const int wr = T::wave_row(), wc = T::wave_col();
-  const int r = lane & 31, h = lane >> 5;
-  const int f = dma_swizzle(r);
-
-  al.issue(kbeg, lds);
-  bl.issue(kbeg, lds + OFFB);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  lds_barrier();
-  for (int ks = kbeg; ks < kend; ++ks) {
-    const int cur = (ks - kbeg) & 1;
-    if (ks + 1 < kend) {
-      al.issue(ks + 1, lds + (cur ^ 1) * BUF);
-      bl.issue(ks + 1, lds + (cur ^ 1) * BUF + OFFB);
-    }
-    const float* pa = lds + cur * BUF + (wr * WM * 32 + r) * BK;
-    const float* pb = lds + cur * BUF + OFFB + (wc * WN * 32 + r) * BK;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      // logical chunks 2h+4s and 2h+4s+1 (k = 16s + 8h .. +7), XOR-swizzled
-      const int c0 = ((2 * h + 4 * s) ^ f) * 4, c1 = ((2 * h + 4 * s + 1) ^ f) * 4;
-      f32x4 fa[WM][2], fb[WN][2];
-#pragma unroll
-      for (int m = 0; m < WM; ++m) {
-        fa[m][0] = *reinterpret_cast<const f32x4*>(pa + m * 32 * BK + c0);
-        fa[m][1] = *reinterpret_cast<const f32x4*>(pa + m * 32 * BK + c1);
-      }
-#pragma unroll
-      for (int n = 0; n < WN; ++n) {
-        fb[n][0] = *reinterpret_cast<const f32x4*>(pb + n * 32 * BK + c0);
-        fb[n][1] = *reinterpret_cast<const f32x4*>(pb + n * 32 * BK + c1);
-      }
-#pragma unroll
-      for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int m = 0; m < WM; ++m)
-#pragma unroll
-          for (int n = 0; n < WN; ++n)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[m][t >> 2][t & 3], fb[n][t >> 2][t & 3],
-                                                             acc[m][n], 0, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMAs of step ks+1 have landed
-    lds_barrier();                                    // ... and everybody else's
-  }
-}
-
-// Row-major [rows][ld] matrix through LDS-DMA (same role as RowLoader).
-template <int N, int RP>
-struct DmaRowLoader {
-  __amdgpu_buffer_rsrc_t rsrc;
-  uint32_t off0, ldb;
-  __device__ __forceinline__ DmaRowLoader(const float* tile_base, int64_t rows_left, int ld) {
-    const int tid = threadIdx.x;
-    const int64_t rows = rows_left < RP * N ? rows_left : RP * N;
-    rsrc = make_rsrc(tile_base, (uint32_t)(rows * ld * 4));
-    ldb = (uint32_t)ld * 4u;
-    const int r = tid >> 3;
-    off0 = (uint32_t)r * ldb + (uint32_t)(((tid & 7) ^ dma_swizzle(r)) * 16);
-  }
-  __device__ __forceinline__ void issue(int kstep, float* lds_tile) const {
-    const int wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int i = 0; i < N; ++i)
-      dma_load16(rsrc, lds_tile + (wave * 8 + RP * i) * BK, off0 + (uint32_t)kstep * (BK * 4) + (uint32_t)i * RP * ldb);
-  }
-};
+typedef __attribute__((address_space(3))) void* lds_ptr_t;   // destination of buffer_load ... lds (conv.hip: PatchDma)
 
 }  // namespace dif

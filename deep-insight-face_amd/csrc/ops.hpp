@@ -85,7 +85,6 @@ struct ConvArgs {
   unsigned* sk_flag;
   unsigned sk_epoch;
   int sk_max_blocks;
-  int sk_skew_q16;      // stream-K share skew by resident slot, Q16 (conv.hip: sk_begin); filled by conv_run
   int sk_spin_limit;    // polls before the owner computes a missing K range itself; < 0: always (test hook)
   int bdp_mode;         // conv_bdp_kernel for the patch layers: 0 where it pays (conv.hip: conv_bdp_ok), 1 never (set where
                         // launches are short and the lanes run half-chip grids: measured 1-2 % slower there; Net option
