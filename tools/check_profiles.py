@@ -52,7 +52,8 @@ def main():
         cp('bench_%s.json' % w, '%s_%s_bench.json' % (R, w))
     for src, dst in (('layers_r100.txt', 'r100_b256_layers.txt'), ('layers_r50.txt', 'r50_b256_layers.txt'),
                      ('layers_r100_bf16x3.txt', 'r100_b256_bf16x3_layers.txt'), ('layers_yolov3.txt', 'yolov3_b64_layers.txt'),
-                     ('latency.txt', 'latency.txt')):
+                     ('latency.txt', 'latency.txt'), ('batch_sweep.txt', 'batch_sweep.txt'), ('zero_weights.txt', 'bf16x3_zero_weights.txt'),
+                     ('match_ab.txt', 'match_filter_ab.txt')):
         cp(src, R + '_' + src.replace(src, dst))
     # forwards per profiled run, in units of the workload's batch: bench.py reports them (`forwards_in_process`:
     # steps + warmup, the per-layer profile, the warm-up and the stamped forward of the clock measurement, and the
