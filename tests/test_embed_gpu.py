@@ -303,6 +303,29 @@ def test_deferred_epilogue_kernel_equals_plain_kernel(cuda, monkeypatch):
             monkeypatch.delenv('DIF_SK_SPIN_LIMIT')
 
 
+def test_lean_epilogue_equals_general_epilogue(cuda):
+    """conv_igemm_kernel finishes a tile through conv_epilogue_fast when the output is plain (whole tensor, Cout % 4 == 0,
+    unit-stride shortcut, 32-bit offsets) and through the general conv_epilogue otherwise; option 'dbg' bit 1024 keeps every
+    layer on the general one.  Same operations per element in the same order: bit-identical embeddings, on networks that
+    cover ReLU / PReLU / ReLU6 / no activation, shortcuts prefetched in the mainloop's tail and fetched in the epilogue,
+    8x8-tile and linear patches, stream-K partial tiles and the split-bf16 kernel's 128 x 128 tile."""
+    import torch
+    from deep_insight_face.networks.triplet import DifEmbedder
+    rng = np.random.default_rng(45)
+    for arch, n, compute in (('iresnet50', 37, 'f32'), ('resnet', 70, 'f32'), ('mobilenet', 20, 'f32'), ('vgg16', 5, 'f32'),
+                             ('iresnet50', 96, 'bf16x3')):
+        x = torch.from_numpy(rng.integers(0, 256, (n, 112, 112, 3), dtype=np.uint8)).cuda()
+        m = DifEmbedder(arch, 'v2', 512, (112, 112, 3), max_batch=n, compute=compute).init_synthetic(12)
+        m.set_input_transform(scale=1 / 255.)
+        m.set_option('bdp', 0)                 # keep the 3x3 layers on conv_igemm_kernel, whose epilogue this is
+        a = m.embed(x)
+        m.set_option('dbg', 1024)
+        b = m.embed(x)
+        m.set_option('dbg', 0)
+        assert torch.equal(a, b), (arch, compute, float((a - b).abs().max()))
+        m.close()
+
+
 def test_stem_kernels_equal_general_kernel(cuda):
     """3-channel first layers run on their own kernels: IResNet's 3x3 and ResNet50V2's 7x7 / stride 2 (64 filters) on
     the MFMA with the input patch in LDS and the true K (stem.hip), YOLOv3-face's 3x3 (32 filters) as a direct
