@@ -398,7 +398,8 @@ def test_embed_full_batch_properties(cuda):
     model.close()
 
 
-@pytest.mark.parametrize('arch,head,emd,n', [('iresnet50', 'v2', 512, 96), ('iresnet100', 'v2', 512, 64),
+@pytest.mark.parametrize('arch,head,emd,n', [('iresnet50', 'v2', 512, 96), ('iresnet50', 'v2', 512, 37), ('iresnet50', 'v2', 512, 130),
+                                             ('iresnet100', 'v2', 512, 64),
                                              ('resnet', 'v2', 512, 512), ('resnet', 'v1', 128, 512),
                                              ('vgg16', 'v2', 512, 16)])
 def test_embed_bf16x3_mode_vs_oracle(cuda, arch, head, emd, n):
