@@ -665,6 +665,77 @@ struct PatchDma {
   }
 };
 
+// The same operand for maps whose sides are multiples of 8 and too wide for the linear patch (the 56 x 56 and 112 x 112
+// stages): the 128-pixel tile is TWO consecutive 8 x 8 tiles of the 8x8-tile order (tile2d_pix0; they need not be neighbours,
+// the second may lie in the next row of tiles or in the next image), each with its own 10 x 10 patch: entries 0..99 and
+// 100..199.  Wave row wr works on sub-tile wr; tap (kh, kw) = entry offset 10 kh + kw.
+template <class T>
+struct PatchDma2D {
+  static constexpr int EMAX = 200, SIDE = 10;
+  static constexpr int NPC = (EMAX * 8 + T::NT - 1) / T::NT;
+  static_assert(T::BM == 128 && T::WGM == 2 && T::WM == 2, "two 8x8 sub-tiles, one per wave row");
+  __amdgpu_buffer_rsrc_t rsrc;
+  int base[T::WM];
+  int WP, H, W, Cin4;
+  int hw0[2], ioff[2];      // per sub-tile: (h0 - 1) << 16 | (w0 - 1) & 0xffff, and its image's offset in pixels from the first image
+  __device__ __forceinline__ PatchDma2D(const ConvArgs& a, int m0) {
+    const int lane = threadIdx.x & 63;
+    WP = SIDE;
+    H = a.H;
+    W = a.W;
+    Cin4 = a.Cin * 4;
+    int n0, h0, w0, n1, h1, w1;
+    tile2d_pix0(a, m0, n0, h0, w0);
+    const bool second = m0 + 64 < a.M;
+    tile2d_pix0(a, second ? m0 + 64 : m0, n1, h1, w1);
+    const int64_t img_elems = (int64_t)a.H * a.W * a.Cin;
+    rsrc = make_rsrc(a.x + n0 * img_elems, (uint32_t)((n1 - n0 + 1) * img_elems * 4));
+    hw0[0] = ((h0 - 1) << 16) | ((w0 - 1) & 0xffff);
+    hw0[1] = second ? (((h1 - 1) << 16) | ((w1 - 1) & 0xffff)) : (int)0xc000c000;     // far outside: every entry reads zero
+    ioff[0] = 0;
+    ioff[1] = (n1 - n0) * a.H * a.W;
+#pragma unroll
+    for (int mi = 0; mi < T::WM; ++mi) {
+      const int r = mi * 32 + (lane & 31);                 // row inside the wave row's sub-tile
+      base[mi] = T::wave_row() * 100 + (r >> 3) * SIDE + (r & 7);
+    }
+  }
+  __device__ __forceinline__ void issue(int cblk, char* staging) const {
+    const int wave = threadIdx.x >> 6;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));                          // recompute the offsets per slice (see PatchDma)
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      const int slot = tid + T::NT * j;
+      const int e = slot >> 3, q = slot & 7;
+      const int sub = e >= 100 ? 1 : 0, el = e - 100 * sub;
+      const int py = (el * 205) >> 11, px = el - py * SIDE;          // el / 10 for el < 1024
+      const int hi = (hw0[sub] >> 16) + py, wi = (int)(short)(hw0[sub] & 0xffff) + px;
+      const bool ok = e < EMAX && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+      const uint32_t off = ok ? (uint32_t)((ioff[sub] + hi * W + wi) * Cin4 + q * 16 + cblk * 128) : OOB;
+      if ((wave * 64 + T::NT * j) < EMAX * 8)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(staging + (wave * 64 + T::NT * j) * 16), 16, off, 0, 0, 0);
+    }
+  }
+  __device__ __forceinline__ void convert(const char* staging, char* planes) const {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      const int slot = tid + T::NT * j;
+      if (slot < EMAX * 8) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(staging + slot * 16);
+        u32x2 hi, mid, lo;
+        bf3_split(v, hi, mid, lo);
+        char* w = planes + (slot >> 3) * BF3P_EB + (slot & 7) * 8;
+        *reinterpret_cast<u32x2*>(w) = hi;
+        *reinterpret_cast<u32x2*>(w + 64) = mid;
+        *reinterpret_cast<u32x2*>(w + 128) = lo;
+      }
+    }
+  }
+};
+
 // K-steps [9 cbeg, 9 cend): whole 32-channel slices (the kernel cuts its stream-K shares at slice boundaries).  One slice =
 // nine taps = 18 sub-steps of 24 MFMAs, written out as straight-line code: the tap is a compile-time constant (an immediate
 // address offset), nothing is carried through a branch, and three rings turn at fixed phase --
@@ -677,7 +748,7 @@ template <class T, class PA>
 __device__ __forceinline__ void gemm_mainloop_patch_bf3(const PA& pa, const ConvArgs& a, int n0, int cbeg, int cend,
                                                         char* lds, f32x16 (&acc)[T::WM][T::WN]) {
   constexpr int WM = T::WM, WN = T::WN;
-  static_assert(WM * WN == 4, "split-bf16 patch path: four accumulator fragments per wave");
+  static_assert((WM == 2 && (WN == 1 || WN == 2)) || (WM == 4 && WN == 1), "split-bf16 patch path: wave tiles 64 x 64, 64 x 32, 128 x 32");
   const int lane = threadIdx.x & 63, h = lane >> 5;
   const int KS = a.Kpad / BK;
   char* staging = lds + bf3p_planes_b(T::BM);
@@ -732,7 +803,7 @@ __device__ __forceinline__ void gemm_mainloop_patch_bf3(const PA& pa, const Conv
   // WEIGHTS -- same instructions, same loads, same bytes -- it runs 20 % faster and the clock held inside the kernels goes from
   // 2.06 to 2.38 GHz: six bf16 MFMAs per product on random data are limited by board power, not by this loop's structure.
   constexpr int RING = WN == 1 ? 6 : 3, LOOK = RING - 1;
-  constexpr int FA_SETS = WN == 1 ? 1 : 2;
+  constexpr int FA_SETS = WM == 4 ? 1 : 2;
   static_assert(18 % RING == 0, "ring phase");
   u32x4 bq[RING][WN][3];
   u32x4 fa[FA_SETS][WM][3];
@@ -882,16 +953,21 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
       if (a.res && !res_loaded) er.load(a, m0, n0);
     }
     const bool strided_res = (a.res_stride != 1 || a.res_H != a.Ho || a.res_W != a.Wo);
-    int t2_pix0 = 0;
+    int t2_pix0 = 0, t2_pix1 = 0;
+    bool t2_second = true;
     if constexpr (TILE2D) {
       int n, h0, w0;
       t2_pix0 = tile2d_pix0(a, m0, n, h0, w0);
+      if constexpr (T::BM > 64) {                          // two 8x8 sub-tiles (PatchDma2D)
+        t2_second = m0 + 64 < a.M;
+        t2_pix1 = tile2d_pix0(a, t2_second ? m0 + 64 : m0, n, h0, w0);
+      }
     }
 #pragma unroll
     for (int i = 0; i < ITER; ++i) {
       const int rl = r0 + i * RPP;
-      const int row = TILE2D ? t2_pix0 + (rl >> 3) * a.W + (rl & 7) : m0 + rl;
-      if (row < a.M) {
+      const int row = TILE2D ? (rl < 64 ? t2_pix0 : t2_pix1) + ((rl & 63) >> 3) * a.W + (rl & 7) : m0 + rl;
+      if (TILE2D ? (rl < 64 || t2_second) : row < a.M) {
         f32x4 rres = {0.f, 0.f, 0.f, 0.f};
         if constexpr (PRELOAD) {
           rres = er.rv[i];
@@ -988,10 +1064,15 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvArgs& a, f32x16 (&a
   const f32x4 sc = load4_or(a.scale, cc, 1.f), sh = load4_or(a.shift, cc, 0.f), al = load4_or(a.alpha, cc, 0.f);
   const f32x4 sc2 = load4_or(a.scale2, cc, 1.f), sh2 = load4_or(a.shift2, cc, 0.f), al2 = load4_or(a.alpha2, cc, 0.f);
   const int act = a.act, act2 = a.act2;
-  int t2_pix0 = 0;
+  int t2_pix0 = 0, t2_pix1 = 0;
+  bool t2_second = true;
   if constexpr (TILE2D) {
     int n, h0, w0;
     t2_pix0 = tile2d_pix0(a, m0, n, h0, w0);
+    if constexpr (T::BM > 64) {                            // the split-bf16 kernel's tile: two 8x8 sub-tiles (PatchDma2D)
+      t2_second = m0 + 64 < a.M;
+      t2_pix1 = tile2d_pix0(a, t2_second ? m0 + 64 : m0, n, h0, w0);
+    }
   }
   const bool has_res = a.res != nullptr;
   const float* srow = smem + r0 * CS + c4 * 4;
@@ -1002,8 +1083,9 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvArgs& a, f32x16 (&a
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
       const int rl = r0 + (i0 + j) * RPP;
-      const int row = TILE2D ? t2_pix0 + (rl >> 3) * a.W + (rl & 7) : m0 + rl;
-      voff[j] = (col_ok && row < a.M) ? ((uint32_t)row * (uint32_t)a.Cout + (uint32_t)c) * 4u : OOB;
+      const int row = TILE2D ? (rl < 64 ? t2_pix0 : t2_pix1) + ((rl & 63) >> 3) * a.W + (rl & 7) : m0 + rl;
+      const bool row_ok = TILE2D ? (rl < 64 || t2_second) : row < a.M;
+      voff[j] = (col_ok && row_ok) ? ((uint32_t)row * (uint32_t)a.Cout + (uint32_t)c) * 4u : OOB;
       rv[j] = res_loaded ? er.rv[i0 + j] : (has_res ? buf_load4(res_rsrc, voff[j]) : f32x4{0.f, 0.f, 0.f, 0.f});
     }
 #pragma unroll
@@ -1042,13 +1124,13 @@ struct NoLoader {};   // B operand of the B-direct kernels: fetched by the mainl
 // BF3 (with AM = 13): the split-bf16 patch kernel, gemm_mainloop_patch_bf3 on the fragment-order split weights a.w3f
 template <class T, bool PRE, int AM, bool BF3 = false>
 __global__ __launch_bounds__(T::NT, (BF3 ? 2 : T::MIN_BLOCKS)) void conv_igemm_kernel(const ConvArgs a) {
-  static_assert(!BF3 || (AM == 13 && !PRE), "split-bf16 exists as the B-direct patch kernel only");
+  static_assert(!BF3 || ((AM == 13 || AM == 16) && !PRE), "split-bf16 exists as the B-direct patch kernel only");
   constexpr int AMP = AM % 10;                              // AM >= 10: the B-direct form of patch path AM - 10
   constexpr bool PATCH = (AMP == 3 || AMP == 5 || AMP == 6), BD = AM >= 10;
   static_assert(!BD || PATCH, "B-direct exists for the patch paths only");
   constexpr bool B3P = BF3 && PATCH;                         // split-bf16 patch kernel: gemm_mainloop_patch_bf3
   static_assert(!PATCH || !PRE, "patch path: no pre-activation");
-  static_assert(!PATCH || (B3P ? (BD && T::BN == 128 && AMP == 3) : (T::BM == 64 && T::BN == 64)), "patch path tiles");
+  static_assert(!PATCH || (B3P ? (BD && (AMP == 3 || AMP == 6)) : (T::BM == 64 && T::BN == 64)), "patch path tiles");
   constexpr int WM = T::WM, WN = T::WN;
   constexpr int SLAB = T::BM * T::BN;    // floats per partial-accumulator slab
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1087,7 +1169,8 @@ __global__ __launch_bounds__(T::NT, (BF3 ? 2 : T::MIN_BLOCKS)) void conv_igemm_k
     using ALoadGather = ALoadReg;
     using ALoadLin = typename std::conditional<AMP == 3, typename std::conditional<B3P, PatchDma<T, bf3p_emax(T::BM)>, PatchA<T, PATCH_EMAX_S>>::type,   // AM 3 / 5 / 6: halo-resident patch
                                                typename std::conditional<AMP == 5, PatchA<T, PATCH_EMAX_L>, ALoadGather>::type>::type;
-    using ALoad = typename std::conditional<AMP == 6, PatchA2D<T>, ALoadLin>::type;
+    using ALoad2D = typename std::conditional<B3P, PatchDma2D<typename std::conditional<B3P, T, Tile<2, 2, 2, 2>>::type>, PatchA2D<typename std::conditional<B3P, Tile<1, 1>, T>::type>>::type;
+    using ALoad = typename std::conditional<AMP == 6, ALoad2D, ALoadLin>::type;
     using BLoadF32 = RowLoader<T::NB, T::RP>;
     using BLoad = typename std::conditional<B3P, NoLoader, BLoadF32>::type;
     ALoad al(a, m0);
@@ -1219,7 +1302,8 @@ __global__ __launch_bounds__(T::NT, (BF3 ? 2 : T::MIN_BLOCKS)) void conv_igemm_k
       if (a.epi_fast)
         conv_epilogue_fast<T, AMP == 6>(a, acc, m0, n0, smem, er, whole && a.res != nullptr);
       else
-        conv_epilogue<T, !PATCH || B3P, AMP == 6, !BF3>(a, acc, m0, n0, smem, er, whole);
+        // (EpiRes fetches the shortcut rows of a LINEAR tile: the two-sub-tile form fetches them row by row instead)
+        conv_epilogue<T, !PATCH || (B3P && AMP != 6), AMP == 6, !BF3>(a, acc, m0, n0, smem, er, whole);
     }
     if (a.trace) {
       const unsigned long long tD = __builtin_amdgcn_s_memrealtime();
@@ -1819,11 +1903,22 @@ static int patch_applies(const ConvArgs& a) {
   const int e_bound = patch_entry_bound(a, 64);
   return e_bound <= PATCH_EMAX_S ? PATCH_EMAX_S : (e_bound <= PATCH_EMAX_L ? PATCH_EMAX_L : 0);
 }
-// the split-bf16 patch kernel (128 x 128 tile): layers with at least 128 output channels on maps up to 28 wide
-static bool bf3p_applies(const ConvArgs& a) {
-  if (!a.w3f || !patch_shape(a) || a.y_sub || a.Cout < 128) return false;
-  if (!(a.y_H == a.Ho && a.y_W == a.Wo && a.y_oy == 0 && a.y_ox == 0)) return false;
-  return patch_entry_bound(a, 128) <= bf3p_emax(128);
+// The split-bf16 patch kernel (128-pixel tile, 128 or 64 columns): 1 = linear patch (maps up to 28 wide), 2 = two 8x8
+// sub-tiles (sides multiples of 8), 0 = the layer stays on the f32 kernels.  net.hip asks the same question at finalize
+// (conv_bf3p_form) to decide which weight layout a layer needs.
+int conv_bf3p_form(int H, int W, bool batch_gt1, int Cout) {
+  if (Cout < 64) return 0;
+  const int HW = H * W, WP = W + 2, BM = 128;
+  const int row_wraps = (BM - 2) / W + 1, img_wraps = batch_gt1 ? (BM - 2) / HW + 1 : 0;
+  if ((BM - 1) + 2 * row_wraps + WP * img_wraps + 2 * WP + 4 <= bf3p_emax(128)) return 1;
+  return (H % 8 == 0 && W % 8 == 0 && (int64_t)H * W * Cout < (1 << 28)) ? 2 : 0;
+}
+static int bf3p_applies(const ConvArgs& a) {
+  if (!a.w3f || !patch_shape(a) || a.y_sub) return 0;
+  if (!(a.y_H == a.Ho && a.y_W == a.Wo && a.y_oy == 0 && a.y_ox == 0 && a.y_ld == a.Cout && a.y_coff == 0)) return 0;
+  if (a.Cout % 4 != 0 || (a.res && (a.res_stride != 1 || a.res_H != a.Ho || a.res_W != a.Wo))) return 0;   // the lean epilogue's case
+  if ((int64_t)a.M * a.Cout * 4 >= 0xFFFFFFF0LL || (int64_t)2 * a.H * a.W * a.Cin * 4 >= 0x7fffffffLL) return 0;
+  return conv_bf3p_form(a.H, a.W, true, a.Cout);
 }
 
 // the 8x8-tile form of the patch path (AM = 6): the same layers on maps whose sides are multiples of 8, where the
@@ -1988,7 +2083,13 @@ int conv_run(const ConvArgs& a, hipStream_t st) {
   }
   // (four waves of 128 x 32 with a six-set B ring, and eight waves on a 256 x 128 tile -- Tile<4, 1, 1, 4>, Tile<2, 2, 4, 2>: the
   // mainloop takes either -- measured the same as this one within 2 %)
-  if (bf3p_applies(a)) return launch_conv_pre<Tile<2, 2, 2, 2>, false, 13, true>(a, st);
+  switch (bf3p_applies(a) * 2 + (a.Cout <= 64 ? 1 : 0)) {
+    case 2: return launch_conv_pre<Tile<2, 2, 2, 2>, false, 13, true>(a, st);     // linear patch, 128 columns
+    case 3: return launch_conv_pre<Tile<2, 1, 2, 2>, false, 13, true>(a, st);     // linear patch, 64 columns
+    case 4: return launch_conv_pre<Tile<2, 2, 2, 2>, false, 16, true>(a, st);     // two 8x8 sub-tiles, 128 columns
+    case 5: return launch_conv_pre<Tile<2, 1, 2, 2>, false, 16, true>(a, st);     // two 8x8 sub-tiles, 64 columns
+    default: break;
+  }
   return launch_conv<Tile<1, 1>>(a, st);
 }
 

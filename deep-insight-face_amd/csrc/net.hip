@@ -961,7 +961,7 @@ int Net::finalize(int mb) {
       op.d_w3f = nullptr;
       op.w3f_bytes = 0;
       if (compute_bf16x3 && op.k_order == 1 && op.KH == 3 && op.KW == 3 && op.stride == 1 && op.pad_t == 1 && op.pad_l == 1 &&
-          !op.pre_bn.valid() && op.Cout >= 128) {
+          !op.pre_bn.valid() && conv_bf3p_form(tensors[op.x].H, tensors[op.x].W, true, op.Cout) != 0) {
         // split-bf16 mode, fragment order: [Cout/32][KS][s 2][plane 3][lane 64][8 bf16]
         const int KS = op.Kpad / BK, NT32 = (op.Cout + 31) / 32;
         std::vector<uint16_t> wf((size_t)NT32 * KS * 3072, 0);

@@ -105,6 +105,8 @@ struct ConvArgs {
 int conv_max_blocks();        // persistent blocks the kernel may use on this device
 size_t conv_slab_floats();    // floats per slab
 int conv_run(const ConvArgs& a, hipStream_t st);
+// which form of the split-bf16 kernel a 3x3 / stride 1 layer on an H x W map with Cout filters takes (0: none: f32 kernels)
+int conv_bf3p_form(int H, int W, bool batch_gt1, int Cout);
 
 enum { POOL_MAX = 0, POOL_L2 = 1, POOL_AVG = 2 };
 struct PoolArgs {
