@@ -1299,9 +1299,9 @@ __global__ __launch_bounds__(T::NT, (BF3 ? 2 : T::MIN_BLOCKS)) void conv_igemm_k
       }
       if (a.trace) tC = __builtin_amdgcn_s_memrealtime();
       // (the split-bf16 kernel's operand rings are dead by now: it has the registers to fetch the shortcut tile at once)
-      if (a.epi_fast)
+      if (B3P || a.epi_fast)                                 // (bf3p_applies admits the lean epilogue's case only)
         conv_epilogue_fast<T, AMP == 6>(a, acc, m0, n0, smem, er, whole && a.res != nullptr);
-      else
+      else if constexpr (!B3P)
         // (EpiRes fetches the shortcut rows of a LINEAR tile: the two-sub-tile form fetches them row by row instead)
         conv_epilogue<T, !PATCH || (B3P && AMP != 6), AMP == 6, !BF3>(a, acc, m0, n0, smem, er, whole);
     }

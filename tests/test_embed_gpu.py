@@ -308,12 +308,12 @@ def test_lean_epilogue_equals_general_epilogue(cuda):
     unit-stride shortcut, 32-bit offsets) and through the general conv_epilogue otherwise; option 'dbg' bit 1024 keeps every
     layer on the general one.  Same operations per element in the same order: bit-identical embeddings, on networks that
     cover ReLU / PReLU / ReLU6 / no activation, shortcuts prefetched in the mainloop's tail and fetched in the epilogue,
-    8x8-tile and linear patches, stream-K partial tiles and the split-bf16 kernel's 128 x 128 tile."""
+    8x8-tile and linear patches, stream-K partial tiles.  (The split-bf16 kernel has the lean epilogue only: its dispatch
+    admits nothing else.)"""
     import torch
     from deep_insight_face.networks.triplet import DifEmbedder
     rng = np.random.default_rng(45)
-    for arch, n, compute in (('iresnet50', 37, 'f32'), ('resnet', 70, 'f32'), ('mobilenet', 20, 'f32'), ('vgg16', 5, 'f32'),
-                             ('iresnet50', 96, 'bf16x3')):
+    for arch, n, compute in (('iresnet50', 37, 'f32'), ('resnet', 70, 'f32'), ('mobilenet', 20, 'f32'), ('vgg16', 5, 'f32')):
         x = torch.from_numpy(rng.integers(0, 256, (n, 112, 112, 3), dtype=np.uint8)).cuda()
         m = DifEmbedder(arch, 'v2', 512, (112, 112, 3), max_batch=n, compute=compute).init_synthetic(12)
         m.set_input_transform(scale=1 / 255.)
