@@ -565,7 +565,7 @@ def main():
             gap = float((1 - (ef * e3d).sum(1) / (ef.norm(dim=1) * e3d.norm(dim=1))).max())
             out['throughput_mode'] = {
                 'compute': 'bf16x3 (three bf16 terms per f32 operand, six bf16 MFMA products, f32 accumulation; 3x3 / stride 1 '
-                           'layers from 128 channels up, the other layers stay float32)',
+                           'layers from 64 channels up, the other layers stay float32)',
                 'forward_ms_hip_events': ms3, 'faces_per_s_embed_only': batch / (ms3 * 1e-3),
                 'faces_per_s_with_the_float32_runs_match': batch / ((ms3 + match_ms) * 1e-3),
                 'algorithmic_tflops': flops_embed / (ms3 * 1e-3) / 1e12, 'speedup_vs_float32_forward': embed_ms / ms3,
