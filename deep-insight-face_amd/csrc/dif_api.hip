@@ -101,7 +101,9 @@ int dif_gallery_set(dif_gallery* h, const float* rows_dev, int64_t n, int64_t in
     g.rows = g.rows2 = g.sq = g.ninv = nullptr;
     g.cap = 0;
     DIF_HIP(hipMalloc(&g.rows, (size_t)n * g.d * sizeof(float)));
-    DIF_HIP(hipMalloc(&g.rows2, (size_t)n * g.d * sizeof(float)));
+    // the split-bf16 copy the filter reads: as large as the rows themselves; a gallery whose "filter" option was set to 0
+    // BEFORE its rows does without it (and keeps the f32 filter even if the option is switched back on later)
+    if (g.filter_bf2) DIF_HIP(hipMalloc(&g.rows2, (size_t)n * g.d * sizeof(float)));
     DIF_HIP(hipMalloc(&g.sq, (size_t)n * sizeof(float)));
     DIF_HIP(hipMalloc(&g.ninv, (size_t)n * sizeof(float)));
     g.cap = n;

@@ -119,7 +119,8 @@ int dif_gallery_set(dif_gallery* g, const float* rows_dev, int64_t n, int64_t in
 int64_t dif_gallery_size(const dif_gallery* g);
 /* options.  "filter": 1 (default) the MFMA stage of dif_match -- a candidate filter with a proven error bound; the
  * winner is chosen on the reference's own float32 arithmetic either way -- runs on two-term split-bf16 copies of the
- * gallery and the probes (three bf16 MFMAs per 16 k), 0 on the f32 MFMA; results are identical.
+ * gallery and the probes (three bf16 MFMAs per 16 k), 0 on the f32 MFMA; results are identical.  The split copy of the
+ * gallery doubles its device memory (d * 4 bytes per row more); set "filter" to 0 before dif_gallery_set to do without it.
  * "clamp_nan": 0 (default) dif_match reports NaN where the reference's distance is NaN; 1 reports the
  * distance of the similarity clamped to [-1, 1] instead (0 for a similarity rounded above 1, 1 below -1).  The
  * arg-min is the reference's either way. */
