@@ -1122,7 +1122,9 @@ struct NoLoader {};   // B operand of the B-direct kernels: fetched by the mainl
 // AM (A-operand gather mode): 0 general, 1 pointwise (1x1, no padding, Cin % 32 == 0),
 // 2 multi-tap with Cin % 32 == 0 and channel-block-major K
 // BF3 (with AM = 13): the split-bf16 patch kernel, gemm_mainloop_patch_bf3 on the fragment-order split weights a.w3f
-template <class T, bool PRE, int AM, bool BF3 = false>
+// LEAN: the tile is finished by conv_epilogue_fast (the launcher checked its case), otherwise by the general conv_epilogue --
+// one of the two per instantiation, not both behind a run-time flag
+template <class T, bool PRE, int AM, bool BF3 = false, bool LEAN = false>
 __global__ __launch_bounds__(T::NT, (BF3 ? 2 : T::MIN_BLOCKS)) void conv_igemm_kernel(const ConvArgs a) {
   static_assert(!BF3 || ((AM == 13 || AM == 16) && !PRE), "split-bf16 exists as the B-direct patch kernel only");
   constexpr int AMP = AM % 10;                              // AM >= 10: the B-direct form of patch path AM - 10
@@ -1299,9 +1301,9 @@ __global__ __launch_bounds__(T::NT, (BF3 ? 2 : T::MIN_BLOCKS)) void conv_igemm_k
       }
       if (a.trace) tC = __builtin_amdgcn_s_memrealtime();
       // (the split-bf16 kernel's operand rings are dead by now: it has the registers to fetch the shortcut tile at once)
-      if (B3P || a.epi_fast)                                 // (bf3p_applies admits the lean epilogue's case only)
+      if constexpr (B3P || LEAN)                             // (bf3p_applies admits the lean epilogue's case only)
         conv_epilogue_fast<T, AMP == 6>(a, acc, m0, n0, smem, er, whole && a.res != nullptr);
-      else if constexpr (!B3P)
+      else
         // (EpiRes fetches the shortcut rows of a LINEAR tile: the two-sub-tile form fetches them row by row instead)
         conv_epilogue<T, !PATCH || (B3P && AMP != 6), AMP == 6, !BF3>(a, acc, m0, n0, smem, er, whole);
     }
@@ -2003,9 +2005,22 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
   return launch_conv_pre<T, false, 0>(a, st);
 }
 
+template <class T, bool PRE, int AM, bool BF3, bool LEAN>
+static int launch_conv_pre_impl(const ConvArgs& a, hipStream_t st);
+
 template <class T, bool PRE, int AM, bool BF3>
 static int launch_conv_pre(const ConvArgs& a, hipStream_t st) {
-  auto kern = conv_igemm_kernel<T, PRE, AM, BF3>;
+  // the lean epilogue's case (conv_epilogue_fast)
+  const bool lean = !(a.dbg & 1024) && a.y_H == a.Ho && a.y_W == a.Wo && a.y_oy == 0 && a.y_ox == 0 && a.y_ld == a.Cout &&
+                    a.y_coff == 0 && !a.y_sub && a.Cout % 4 == 0 &&
+                    (!a.res || (a.res_stride == 1 && a.res_H == a.Ho && a.res_W == a.Wo)) && (int64_t)a.M * a.Cout * 4 < 0xFFFFFFF0LL;
+  if constexpr (BF3) return launch_conv_pre_impl<T, PRE, AM, BF3, true>(a, st);
+  else return lean ? launch_conv_pre_impl<T, PRE, AM, BF3, true>(a, st) : launch_conv_pre_impl<T, PRE, AM, BF3, false>(a, st);
+}
+
+template <class T, bool PRE, int AM, bool BF3, bool LEAN>
+static int launch_conv_pre_impl(const ConvArgs& a, hipStream_t st) {
+  auto kern = conv_igemm_kernel<T, PRE, AM, BF3, LEAN>;
   constexpr int AMP = AM % 10;
   constexpr int emax = AMP == 3 ? PATCH_EMAX_S : (AMP == 5 ? PATCH_EMAX_L : 100);
   constexpr int epi_bytes = T::BM * (T::BN + 4) * 4;       // the epilogue's staging tile
@@ -2047,10 +2062,7 @@ static int launch_conv_pre(const ConvArgs& a, hipStream_t st) {
   b.fd_t2_img = make_fastdiv((a.H / 8) * (a.W / 8) > 0 ? (a.H / 8) * (a.W / 8) : 1);
   if (a.k_order == 1 && a.Cin % BK != 0) return set_error("conv: channel-block-major K order needs Cin %% 32 == 0");
   b.fd_tiles_n = make_fastdiv((a.Cout + T::BN - 1) / T::BN);
-  // the lean epilogue's case (conv_epilogue_fast)
-  b.epi_fast = !(a.dbg & 1024) && a.y_H == a.Ho && a.y_W == a.Wo && a.y_oy == 0 && a.y_ox == 0 && a.y_ld == a.Cout && a.y_coff == 0 &&
-               !a.y_sub && a.Cout % 4 == 0 && (!a.res || (a.res_stride == 1 && a.res_H == a.Ho && a.res_W == a.Wo)) &&
-               (int64_t)a.M * a.Cout * 4 < 0xFFFFFFF0LL;
+  b.epi_fast = LEAN;
   hipLaunchKernelGGL(kern, dim3((unsigned)P), dim3(T::NT), lds_bytes, st, b);
   DIF_HIP(hipGetLastError());
   return 0;
