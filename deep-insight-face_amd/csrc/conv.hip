@@ -1036,7 +1036,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
 // (net.hip: option dbg = 256) showed 13-17 us of epilogue per 64 x 64 tile against 18 us of mainloop on the 64-channel layers.
 // Here every access is a buffer access with a 32-bit offset (out-of-range = dropped / zero replaces each predicate, a null
 // tensor gets an empty descriptor), the shortcut rows of a group are requested together, and nothing is carried but the offsets.
-template <class T, bool TILE2D>
+template <class T, bool TILE2D, bool YSUB = false>
 __device__ __forceinline__ void conv_epilogue_fast(const ConvArgs& a, f32x16 (&acc)[T::WM][T::WN], int m0, int n0,
                                                    float* smem, const EpiRes<T>& er, bool res_loaded) {
   constexpr int WM = T::WM, WN = T::WN;
@@ -1057,7 +1057,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvArgs& a, f32x16 (&a
   const int c = n0 + c4 * 4;
   const bool col_ok = c < a.Cout;
   const uint32_t bytes = (uint32_t)a.M * (uint32_t)a.Cout * 4u;
-  const __amdgpu_buffer_rsrc_t y_rsrc = make_rsrc(a.y, a.y ? bytes : 0u);
+  const __amdgpu_buffer_rsrc_t y_rsrc = make_rsrc(a.y, (a.y && !YSUB) ? bytes : 0u);
   const __amdgpu_buffer_rsrc_t y2_rsrc = make_rsrc(a.y2, a.y2 ? bytes : 0u);
   const __amdgpu_buffer_rsrc_t res_rsrc = make_rsrc(a.res, a.res ? bytes : 0u);
   const int cc = col_ok ? c : 0;
@@ -1074,11 +1074,15 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvArgs& a, f32x16 (&a
       t2_pix1 = tile2d_pix0(a, t2_second ? m0 + 64 : m0, n, h0, w0);
     }
   }
+  // YSUB: the first output keeps its even pixels only, densely (ConvArgs::y_sub); the second output and the shortcut are whole
+  const int hs = (a.Ho + 1) >> 1, ws = (a.Wo + 1) >> 1;
+  const __amdgpu_buffer_rsrc_t ys_rsrc = make_rsrc(a.y, (a.y && YSUB) ? (uint32_t)a.N * (uint32_t)(hs * ws) * (uint32_t)a.Cout * 4u : 0u);
   const bool has_res = a.res != nullptr;
   const float* srow = smem + r0 * CS + c4 * 4;
 #pragma unroll
   for (int i0 = 0; i0 < ITER; i0 += CH) {
     uint32_t voff[CH];
+    int prow[CH];
     f32x4 rv[CH];
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
@@ -1086,6 +1090,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvArgs& a, f32x16 (&a
       const int row = TILE2D ? (rl < 64 ? t2_pix0 : t2_pix1) + ((rl & 63) >> 3) * a.W + (rl & 7) : m0 + rl;
       const bool row_ok = TILE2D ? (rl < 64 || t2_second) : row < a.M;
       voff[j] = (col_ok && row_ok) ? ((uint32_t)row * (uint32_t)a.Cout + (uint32_t)c) * 4u : OOB;
+      prow[j] = row;
       rv[j] = res_loaded ? er.rv[i0 + j] : (has_res ? buf_load4(res_rsrc, voff[j]) : f32x4{0.f, 0.f, 0.f, 0.f});
     }
 #pragma unroll
@@ -1103,7 +1108,16 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvArgs& a, f32x16 (&a
         const float ur = fmaxf(u, 0.f), up = u >= 0.f ? u : u * al2[e];
         v2[e] = act2 == ACT_RELU ? ur : (act2 == ACT_PRELU ? up : (act2 == ACT_RELU6 ? fminf(ur, 6.f) : u));
       }
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), y_rsrc, voff[j], 0, 0);
+      if constexpr (YSUB) {
+        int img, rr, ho, wo;
+        a.fd_howo.divmod(voff[j] == OOB ? 0 : prow[j], img, rr);
+        a.fd_wo.divmod(rr, ho, wo);
+        const uint32_t vs = (voff[j] != OOB && !((ho | wo) & 1))
+                                ? ((uint32_t)((img * hs + (ho >> 1)) * ws + (wo >> 1)) * (uint32_t)a.Cout + (uint32_t)c) * 4u : OOB;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ys_rsrc, vs, 0, 0);
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), y_rsrc, voff[j], 0, 0);
+      }
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v2), y2_rsrc, voff[j], 0, 0);
     }
   }
@@ -1124,7 +1138,7 @@ struct NoLoader {};   // B operand of the B-direct kernels: fetched by the mainl
 // BF3 (with AM = 13): the split-bf16 patch kernel, gemm_mainloop_patch_bf3 on the fragment-order split weights a.w3f
 // LEAN: the tile is finished by conv_epilogue_fast (the launcher checked its case), otherwise by the general conv_epilogue --
 // one of the two per instantiation, not both behind a run-time flag
-template <class T, bool PRE, int AM, bool BF3 = false, bool LEAN = false>
+template <class T, bool PRE, int AM, bool BF3 = false, int LEAN = 0>   // LEAN: 0 general, 1 lean, 2 lean + sub-sampled first output
 __global__ __launch_bounds__(T::NT, (BF3 ? 2 : T::MIN_BLOCKS)) void conv_igemm_kernel(const ConvArgs a) {
   static_assert(!BF3 || ((AM == 13 || AM == 16) && !PRE), "split-bf16 exists as the B-direct patch kernel only");
   constexpr int AMP = AM % 10;                              // AM >= 10: the B-direct form of patch path AM - 10
@@ -1301,7 +1315,9 @@ __global__ __launch_bounds__(T::NT, (BF3 ? 2 : T::MIN_BLOCKS)) void conv_igemm_k
       }
       if (a.trace) tC = __builtin_amdgcn_s_memrealtime();
       // (the split-bf16 kernel's operand rings are dead by now: it has the registers to fetch the shortcut tile at once)
-      if constexpr (B3P || LEAN)                             // (bf3p_applies admits the lean epilogue's case only)
+      if constexpr (LEAN == 2)
+        conv_epilogue_fast<T, AMP == 6, true>(a, acc, m0, n0, smem, er, whole && a.res != nullptr);
+      else if constexpr (B3P || LEAN == 1)                   // (bf3p_applies admits the lean epilogue's cases only)
         conv_epilogue_fast<T, AMP == 6>(a, acc, m0, n0, smem, er, whole && a.res != nullptr);
       else
         // (EpiRes fetches the shortcut rows of a LINEAR tile: the two-sub-tile form fetches them row by row instead)
@@ -1761,7 +1777,9 @@ __global__ __launch_bounds__(T::NT, T::MIN_BLOCKS) void conv_bdp_kernel(const Co
   flush();                                                 // the last tile has no successor to hide behind
   if (a.trace && tid == 0) {
     unsigned long long* t = a.trace + (size_t)blockIdx.x * 8;
-    t[0] = t[1] = t[2] = t[3] = t[4] = 0;
+    t[0] = t[1] = t[2] = t[3] = 0;
+    // where the block ran: HW_ID (wave / SIMD / CU / SH / SE fields) and XCC_ID, for the placement statistics of dbg = 512
+    t[4] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
     t[5] = tr_t0;
     t[6] = __builtin_amdgcn_s_memrealtime();
     t[7] = 1 | ((__builtin_amdgcn_s_memtime() - tr_c0) << 8);
@@ -1916,7 +1934,7 @@ int conv_bf3p_form(int H, int W, bool batch_gt1, int Cout) {
   return (H % 8 == 0 && W % 8 == 0 && (int64_t)H * W * Cout < (1 << 28)) ? 2 : 0;
 }
 static int bf3p_applies(const ConvArgs& a) {
-  if (!a.w3f || !patch_shape(a) || a.y_sub) return 0;
+  if (!a.w3f || !patch_shape(a)) return 0;                 // (a sub-sampled first output is fine: epilogue variant 2)
   if (!(a.y_H == a.Ho && a.y_W == a.Wo && a.y_oy == 0 && a.y_ox == 0 && a.y_ld == a.Cout && a.y_coff == 0)) return 0;
   if (a.Cout % 4 != 0 || (a.res && (a.res_stride != 1 || a.res_H != a.Ho || a.res_W != a.Wo))) return 0;   // the lean epilogue's case
   if ((int64_t)a.M * a.Cout * 4 >= 0xFFFFFFF0LL || (int64_t)2 * a.H * a.W * a.Cin * 4 >= 0x7fffffffLL) return 0;
@@ -2005,7 +2023,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
   return launch_conv_pre<T, false, 0>(a, st);
 }
 
-template <class T, bool PRE, int AM, bool BF3, bool LEAN>
+template <class T, bool PRE, int AM, bool BF3, int LEAN>
 static int launch_conv_pre_impl(const ConvArgs& a, hipStream_t st);
 
 template <class T, bool PRE, int AM, bool BF3>
@@ -2014,11 +2032,11 @@ static int launch_conv_pre(const ConvArgs& a, hipStream_t st) {
   const bool lean = !(a.dbg & 1024) && a.y_H == a.Ho && a.y_W == a.Wo && a.y_oy == 0 && a.y_ox == 0 && a.y_ld == a.Cout &&
                     a.y_coff == 0 && !a.y_sub && a.Cout % 4 == 0 &&
                     (!a.res || (a.res_stride == 1 && a.res_H == a.Ho && a.res_W == a.Wo)) && (int64_t)a.M * a.Cout * 4 < 0xFFFFFFF0LL;
-  if constexpr (BF3) return launch_conv_pre_impl<T, PRE, AM, BF3, true>(a, st);
-  else return lean ? launch_conv_pre_impl<T, PRE, AM, BF3, true>(a, st) : launch_conv_pre_impl<T, PRE, AM, BF3, false>(a, st);
+  if constexpr (BF3) return a.y_sub ? launch_conv_pre_impl<T, PRE, AM, BF3, 2>(a, st) : launch_conv_pre_impl<T, PRE, AM, BF3, 1>(a, st);
+  else return lean ? launch_conv_pre_impl<T, PRE, AM, BF3, 1>(a, st) : launch_conv_pre_impl<T, PRE, AM, BF3, 0>(a, st);
 }
 
-template <class T, bool PRE, int AM, bool BF3, bool LEAN>
+template <class T, bool PRE, int AM, bool BF3, int LEAN>
 static int launch_conv_pre_impl(const ConvArgs& a, hipStream_t st) {
   auto kern = conv_igemm_kernel<T, PRE, AM, BF3, LEAN>;
   constexpr int AMP = AM % 10;
@@ -2062,7 +2080,7 @@ static int launch_conv_pre_impl(const ConvArgs& a, hipStream_t st) {
   b.fd_t2_img = make_fastdiv((a.H / 8) * (a.W / 8) > 0 ? (a.H / 8) * (a.W / 8) : 1);
   if (a.k_order == 1 && a.Cin % BK != 0) return set_error("conv: channel-block-major K order needs Cin %% 32 == 0");
   b.fd_tiles_n = make_fastdiv((a.Cout + T::BN - 1) / T::BN);
-  b.epi_fast = LEAN;
+  b.epi_fast = LEAN != 0;
   hipLaunchKernelGGL(kern, dim3((unsigned)P), dim3(T::NT), lds_bytes, st, b);
   DIF_HIP(hipGetLastError());
   return 0;

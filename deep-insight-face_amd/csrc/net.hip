@@ -20,6 +20,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
 
 #include "../../include/dif.h"
 #include "dif_internal.hpp"
@@ -1522,6 +1523,67 @@ int Net::embed_clock(const void* xin, int n, int layout, int dtype, float* out, 
         fprintf(stderr, "trace %-22s blocks %5d span %7.1f us | life mean %7.1f min %7.1f max %7.1f | main %6.1f fix %6.1f epi %6.1f us/block | "
                         "steps/block %.1f tiles/block %.2f\n", ops[i].name.c_str(), nb, (double)(t_hi - t_lo) / 100.0, life / nb / 100.0,
                 mn / 100.0, mx / 100.0, m / nb / 100.0, f / nb / 100.0, e / nb / 100.0, steps / nb, tiles / nb);
+    }
+  }
+  if (conv_dbg & 512) {
+    // development aid: placement of the blocks of the persistent B-direct launches -- per XCD and per CU, how many blocks ran
+    // there, how long they lived and at what clock (records whose t[4] carries HW_ID / XCC_ID: conv_bdp_kernel)
+    for (size_t i = 0; i < ops.size(); ++i) {
+      if (ops[i].kind != OP_CONV) continue;
+      const size_t end = i + 1 < ops.size() ? trace_off[i + 1] : total;
+      std::map<unsigned, std::vector<double>> by_xcd, by_cu;     // -> {blocks, sum life, sum cycles, max end}
+      unsigned long long t_lo = ~0ull;
+      for (size_t b = trace_off[i]; b < end; ++b)
+        if ((h[b * 8 + 7] & 0xff) == 1 && h[b * 8 + 4] && h[b * 8 + 5] < t_lo) t_lo = h[b * 8 + 5];
+      int nb = 0;
+      for (size_t b = trace_off[i]; b < end; ++b) {
+        const unsigned long long* t = &h[b * 8];
+        if ((t[7] & 0xff) != 1 || !t[4] || t[6] <= t[5]) continue;
+        ++nb;
+        const unsigned hw = (unsigned)t[4], xcc = (unsigned)(t[4] >> 32) & 0xf;
+        const unsigned cu = (xcc << 16) | (hw & 0xff00);          // CU_ID [11:8], SH_ID [12], SE_ID [15:13]
+        for (auto* mp : {&by_xcd[xcc], &by_cu[cu]}) {
+          if (mp->empty()) mp->assign(5, 0.0);
+          (*mp)[0] += 1;
+          (*mp)[1] += (double)(t[6] - t[5]);
+          (*mp)[2] += (double)(t[7] >> 8);
+          (*mp)[3] = std::max((*mp)[3], (double)(t[6] - t_lo));
+          (*mp)[4] += (double)(t[5] - t_lo);
+        }
+      }
+      if (!nb) continue;
+      fprintf(stderr, "place %-20s blocks %d on %zu CUs |", ops[i].name.c_str(), nb, by_cu.size());
+      for (auto& kv : by_xcd)
+        fprintf(stderr, " xcd%u: %d blk life %.0f us end %.0f us %.2f GHz |", kv.first, (int)kv.second[0], kv.second[1] / kv.second[0] / 100.0,
+                kv.second[3] / 100.0, kv.second[2] / (kv.second[1] * 10.0));
+      std::map<int, std::vector<double>> hist;                     // blocks per CU -> {CUs, sum mean life, sum end, sum start}
+      for (auto& kv : by_cu) {
+        auto& hrec = hist[(int)kv.second[0]];
+        if (hrec.empty()) hrec.assign(4, 0.0);
+        hrec[0] += 1;
+        hrec[1] += kv.second[1] / kv.second[0];
+        hrec[2] += kv.second[3];
+        hrec[3] += kv.second[4] / kv.second[0];
+      }
+      for (auto& kv : hist)
+        fprintf(stderr, " %d/CU: %d CUs life %.0f start %.0f end %.0f us |", kv.first, (int)kv.second[0], kv.second[1] / kv.second[0] / 100.0,
+                kv.second[3] / kv.second[0] / 100.0, kv.second[2] / kv.second[0] / 100.0);
+      // by dispatch round (block index / CUs: the blocks of one round are the n-th residents of their CUs) and by wave slot
+      double rl[8] = {0}, rn[8] = {0}, wl[16] = {0}, wn[16] = {0};
+      for (size_t b = trace_off[i]; b < end; ++b) {
+        const unsigned long long* t = &h[b * 8];
+        if ((t[7] & 0xff) != 1 || !t[4] || t[6] <= t[5]) continue;
+        const size_t r = std::min<size_t>((b - trace_off[i]) / by_cu.size(), 7);
+        rl[r] += (double)(t[6] - t[5]);
+        rn[r] += 1;
+        wl[t[4] & 0xf] += (double)(t[6] - t[5]);
+        wn[t[4] & 0xf] += 1;
+      }
+      for (int r = 0; r < 8; ++r)
+        if (rn[r] > 0) fprintf(stderr, " round%d: %.0f us (%d) |", r, rl[r] / rn[r] / 100.0, (int)rn[r]);
+      for (int r = 0; r < 16; ++r)
+        if (wn[r] > 0) fprintf(stderr, " slot%d: %.0f us (%d) |", r, wl[r] / wn[r] / 100.0, (int)wn[r]);
+      fprintf(stderr, "\n");
     }
   }
   double cyc = 0, ticks = 0;
