@@ -100,6 +100,7 @@ int dif_gallery_set(dif_gallery* h, const float* rows_dev, int64_t n, int64_t in
     if (g.ninv) DIF_HIP(hipFree(g.ninv));
     g.rows = g.rows2 = g.sq = g.ninv = nullptr;
     g.cap = 0;
+    g.n = 0;                                               // an allocation failure below leaves an EMPTY gallery, not dangling rows
     DIF_HIP(hipMalloc(&g.rows, (size_t)n * g.d * sizeof(float)));
     // the split-bf16 copy the filter reads: as large as the rows themselves; a gallery whose "filter" option was set to 0
     // BEFORE its rows does without it (and keeps the f32 filter even if the option is switched back on later)

@@ -1500,6 +1500,7 @@ int Net::embed_clock(const void* xin, int n, int layout, int dtype, float* out, 
       const size_t end = i + 1 < ops.size() ? trace_off[i + 1] : total;
       unsigned long long t_lo = ~0ull, t_hi = 0;
       double life = 0, mn = 1e30, mx = 0, m = 0, f = 0, e = 0, steps = 0, tiles = 0;
+      double p_set = 0, p_pro = 0, p_steps = 0, p_hand = 0, p_tiles = 0;
       int nb = 0;
       for (size_t b = trace_off[i]; b < end; ++b) {
         const unsigned long long* t = &h[b * 8];
@@ -1511,6 +1512,13 @@ int Net::embed_clock(const void* xin, int n, int layout, int dtype, float* out, 
         life += l;
         mn = l < mn ? l : mn;
         mx = l > mx ? l : mx;
+        if ((t[7] & 0xff) == 2) {                          // conv_pipe_kernel: set-up / prologue / K-steps / hand-over, tiles
+          p_set += (double)t[0];
+          p_pro += (double)t[1];
+          p_steps += (double)t[2];
+          p_hand += (double)t[3];
+          p_tiles += (double)t[4];
+        }
         if ((t[7] & 0xff) == 1) {
           m += (double)t[0];
           f += (double)t[1];
@@ -1523,6 +1531,9 @@ int Net::embed_clock(const void* xin, int n, int layout, int dtype, float* out, 
         fprintf(stderr, "trace %-22s blocks %5d span %7.1f us | life mean %7.1f min %7.1f max %7.1f | main %6.1f fix %6.1f epi %6.1f us/block | "
                         "steps/block %.1f tiles/block %.2f\n", ops[i].name.c_str(), nb, (double)(t_hi - t_lo) / 100.0, life / nb / 100.0,
                 mn / 100.0, mx / 100.0, m / nb / 100.0, f / nb / 100.0, e / nb / 100.0, steps / nb, tiles / nb);
+      if (nb && p_tiles > 0)
+        fprintf(stderr, "      pipelined: %.2f tiles/block | per tile: set-up %.2f prologue %.2f K-steps %.2f hand-over %.2f us\n", p_tiles / nb,
+                p_set / p_tiles / 100.0, p_pro / p_tiles / 100.0, p_steps / p_tiles / 100.0, p_hand / p_tiles / 100.0);
     }
   }
   if (conv_dbg & 512) {

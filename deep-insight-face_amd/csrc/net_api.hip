@@ -79,9 +79,9 @@ int dif_net_get_param(const dif_net* h, const char* name, float* data_host, int6
 
 int dif_net_set_input_transform(dif_net* h, float scale, const float bias[3], int flags) {
   if (!h) return set_error("dif_net_set_input_transform: null handle");
+  if (flags & ~(DIF_INPUT_BGR | DIF_INPUT_HFLIP)) return set_error("dif_net_set_input_transform: unknown flags");
   h->net.in_scale = scale;
   for (int k = 0; k < 3; ++k) h->net.in_bias[k] = bias ? bias[k] : 0.f;
-  if (flags & ~(DIF_INPUT_BGR | DIF_INPUT_HFLIP)) return set_error("dif_net_set_input_transform: unknown flags");
   h->net.bgr = flags;
   return 0;
 }
