@@ -72,9 +72,12 @@ def main():
          R + '_r50_b256_hbm_traffic.json')
     tool('pmc_mfma.py', [os.path.join(OUT, 'pm_default/p_counter_collection.csv')], R + '_r100_1m_mfma_util.json')
     tool('pmc_mfma.py', [os.path.join(OUT, 'pm_bf16x3/p_counter_collection.csv')], R + '_r100_1m_bf16x3_mfma_util.json')
-    for src, dst in (('trace_r100_f32.txt', '_r100_b256_block_trace.txt'), ('trace_r100_bf16x3.txt', '_r100_b256_bf16x3_block_trace.txt')):
+    for src, dst in (('trace_r100_f32.txt', '_r100_b256_block_trace.txt'), ('trace_r100_bf16x3.txt', '_r100_b256_bf16x3_block_trace.txt'),
+                     ('trace_r50_f32.txt', '_r50_b256_block_trace.txt'), ('place_r100_f32.txt', '_r100_b256_block_placement.txt')):
+        if not os.path.exists(os.path.join(OUT, src)):
+            continue
         with open(os.path.join(OUT, src)) as fh, open(os.path.join(PROF, R + dst), 'w') as out:
-            out.writelines(l for l in fh if l.startswith('trace '))
+            out.writelines(l for l in fh if l.startswith(('trace ', 'place ', '      pipelined')))
 
     # cross-check 1: default workload, ONE lane: every forward of the profiled process, in batch-512 equivalents
     one = jl(os.path.join(OUT, 'ks_default_1lane.json'))

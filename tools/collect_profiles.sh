@@ -39,6 +39,8 @@ python3 tools/latency.py > $O/latency.txt 2>&1 &&
 DIF_STREAMS=1 ARGS="--workload r100_1m_bf16x3 --steps 3 --warmup 1 --no-cpu-baseline" prof pm_bf16x3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE &&
 DIF_OPTIONS=dbg=256 python3 tools/bf3_trace.py 256 f32 2> $O/trace_r100_f32.txt > /dev/null &&
 DIF_OPTIONS=dbg=256 python3 tools/bf3_trace.py 256 bf16x3 2> $O/trace_r100_bf16x3.txt > /dev/null &&
+DIF_OPTIONS=dbg=256 python3 tools/bf3_trace.py 256 f32 resnet 2> $O/trace_r50_f32.txt > /dev/null &&
+DIF_OPTIONS=dbg=768 python3 tools/bf3_trace.py 256 f32 2> $O/place_r100_f32.txt > /dev/null &&
 (for b in 64 128 256 512 1024; do python3 tools/time_embed.py iresnet100 $b 2>/dev/null | tail -1; done; for b in 64 128 256 512 1024 2048; do python3 tools/time_embed.py resnet $b 2>/dev/null | tail -1; done) > $O/batch_sweep.txt &&
 python3 tools/bf3_zero.py bf16x3 2>/dev/null | tail -2 > $O/zero_weights.txt && python3 tools/bf3_zero.py f32 2>/dev/null | tail -2 >> $O/zero_weights.txt &&
 python3 tools/match_ab.py 2>/dev/null | tail -4 > $O/match_ab.txt
