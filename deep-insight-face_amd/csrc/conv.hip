@@ -1841,8 +1841,12 @@ static int launch_conv_pipe(const ConvArgs& a, hipStream_t st) {
   constexpr int lds = T::LDS_BYTES;
   if (allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return -1;
   const int64_t tiles = ((a.M + T::BM - 1) / T::BM) * (int64_t)((a.Cout + T::BN - 1) / T::BN);
-  int64_t slots = 4 * (int64_t)num_cus();
-  if (slots > a.sk_max_blocks) slots = a.sk_max_blocks;
+  // The grid is sized for the WHOLE chip even when the lanes split it (ConvArgs::sk_max_blocks = half the resident slots
+  // for the stream-K kernels, whose blocks wait for each other): this kernel's blocks are independent, so the half that does
+  // not fit beside the other lane's launch starts as slots come free -- from either lane -- and fills the staggered ends
+  // in which one or two resident blocks per CU leave the matrix pipes half idle (r03_ablation.txt item 21 e: ResNet-50V2
+  // +2.9 % at batch 256; 3x and 4x the lane's slots gain less, 8x loses; alone on the chip 2x the slots loses 1 %).
+  const int64_t slots = 4 * (int64_t)num_cus();
   const int64_t P = tiles < slots ? tiles : slots;
   ConvArgs b = a;
   b.fd_howo = make_fastdiv(a.Ho * a.Wo);
