@@ -642,7 +642,7 @@ struct PatchDma {
       const bool ok = e < EMAX && hp >= 1 && col >= 1 && col <= W && img < imgs;
       const uint32_t off = ok ? (uint32_t)(((img * H + (hp - 1)) * W + (col - 1)) * Cin4 + q * 16 + cblk * 128) : OOB;
       if ((wave * 64 + T::NT * j) < EMAX * 8)             // wave-uniform: whole instructions beyond the patch are skipped
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(staging + (wave * 64 + T::NT * j) * 16), 16, off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, lds_ptr_of(staging + (wave * 64 + T::NT * j) * 16), 16, off, 0, 0, 0);
     }
   }
   // staging (f32, slot-linear) -> the split planes; every thread converts the slots it fetched itself
@@ -714,7 +714,7 @@ struct PatchDma2D {
       const bool ok = e < EMAX && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
       const uint32_t off = ok ? (uint32_t)((ioff[sub] + hi * W + wi) * Cin4 + q * 16 + cblk * 128) : OOB;
       if ((wave * 64 + T::NT * j) < EMAX * 8)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(staging + (wave * 64 + T::NT * j) * 16), 16, off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, lds_ptr_of(staging + (wave * 64 + T::NT * j) * 16), 16, off, 0, 0, 0);
     }
   }
   __device__ __forceinline__ void convert(const char* staging, char* planes) const {

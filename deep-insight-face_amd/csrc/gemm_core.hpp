@@ -385,5 +385,11 @@ struct RowLoader {
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;   // destination of buffer_load ... lds (conv.hip: PatchDma)
+// LDS pointer of a generic pointer KNOWN to point into LDS: its low 32 bits.  (A plain address-space cast carries a null
+// check -- select on the generic pointer's high half, src_shared_base -- which this compiler folds, for some kernel
+// shapes, into `v_cmp_ne_u32 vcc, 0, src_shared_base`: "Illegal instruction detected: Operand has incorrect register class".)
+__device__ __forceinline__ lds_ptr_t lds_ptr_of(const void* p) {
+  return (lds_ptr_t)(uintptr_t)(uint32_t)(uintptr_t)p;
+}
 
 }  // namespace dif
