@@ -27,6 +27,7 @@
 // The zero halo and every tile tail come from buffer-descriptor range checks (an
 // out-of-range offset loads zeros), so the loaders are branch-free.
 #include "gemm_core.hpp"
+#include <string>
 #include "dif_internal.hpp"
 #include "ops.hpp"
 
@@ -573,7 +574,12 @@ __device__ __forceinline__ void gemm_mainloop_patch_bd(const PA& pa, const ConvA
 //     [Cout/32][Kpad/32][s 2][plane 3][lane 64][8 bf16] <- plane(w[32 nt + (lane & 31)][32 ks + 16 s + 8 (lane >> 5) + t])),
 //     go from L2 straight into the MFMA operand registers, one 16-k sub-step ahead; no LDS, no barrier per K-step.
 // Block = 4 waves, each 64 x 64 (2 x 2 fragments: 64 accumulator registers) -> 128 pixels x 128 channels; two blocks
-// per CU = two waves per SIMD with the full 256-register budget (the gather kernel's 128 registers spilled 200-300).
+// per CU = two waves per SIMD with the full 256-register budget.  That budget is NOT enough for the whole kernel
+// (profiles/r03_resource_usage.txt: the 128-column forms carry 126-141 spilled VGPRs / 508-568 B of scratch per lane at 256
+// VGPRs, the 64-column forms 44-60): the spills sit in set-up, the epilogue and the stream-K fallback copy of the loop; the
+// straight-line slice -- the blocks holding MFMAs -- contains no scratch access, which is what matters, because a scratch
+// reload counts on the in-order vmcnt and would drain the B ring (the round-2 gather kernel at 128 registers spilled 200-300
+// inside its loop).
 // Per wave and K-step: 48 MFMAs (1536 matrix-pipe cycles) against 12 ds_read_b128 and 12 coalesced 1 KB loads.
 constexpr int BF3P_EB = 208;          // bytes per patch entry
 constexpr int BF3P_KSTEP_B = 6144;    // bytes of w3f per (32-column tile, K-step)
@@ -1827,8 +1833,30 @@ static int allow_dynamic_lds(const void* kern, int bytes) {
 }
 
 int conv_max_blocks() { return 4 * num_cus(); }
-size_t conv_slab_floats() { return 256 * 128; }   // per resident slot: published partial + fallback stash, either tile
-                                                   // (1024 x 2 x 64x64 or 512 x 2 x 128x128 floats in all)
+
+// The kernel instantiation the last conv_run of this thread launched, as `family<tile, variant>` (dif_net_op_info:
+// the bench line and the per-layer tables name the kernel that ran, not the family's generic name).
+static thread_local const char* g_last_kernel = "";
+const char* conv_last_kernel() { return g_last_kernel; }
+static const char* am_form(int am) {
+  switch (am) {
+    case 0: return "gather";
+    case 1: return "pointwise";
+    case 3: return "patch128";
+    case 5: return "patch168";
+    case 6: return "patch8x8";
+    case 13: return "patch128+Bdirect";
+    case 15: return "patch168+Bdirect";
+    case 16: return "patch8x8+Bdirect";
+  }
+  return "?";
+}
+template <class T>
+static std::string kernel_label(const char* family, int am, const char* extra = "") {
+  return std::string(family) + "<" + std::to_string(T::BM) + "x" + std::to_string(T::BN) + "," + am_form(am) + extra + ">";
+}
+size_t conv_slab_floats() { return 128 * 128; }   // per resident slot (sk_max_blocks of them): published partial + fallback stash of
+                                                   // either shipped tile -- 1024 x 2 x 64x64 or 512 x 2 x 128x128 floats, 64 MiB per lane
 
 template <class T, bool PRE, int AM, bool BF3 = false>
 static int launch_conv_pre(const ConvArgs& a, hipStream_t st);
@@ -1858,6 +1886,8 @@ static int launch_conv_pipe(const ConvArgs& a, hipStream_t st) {
   b.fd_tiles_n = make_fastdiv((a.Cout + T::BN - 1) / T::BN);
   hipLaunchKernelGGL(kern, dim3((unsigned)P), dim3(T::NT), lds, st, b);
   DIF_HIP(hipGetLastError());
+  static const std::string label = kernel_label<T>("conv_pipe_kernel", AM, PRE ? ",preact" : "");
+  g_last_kernel = label.c_str();
   return 0;
 }
 
@@ -1909,6 +1939,8 @@ static int launch_conv_bdp(const ConvArgs& a, hipStream_t st) {
   b.fd_tiles_n = make_fastdiv((a.Cout + T::BN - 1) / T::BN);
   hipLaunchKernelGGL(kern, dim3((unsigned)P), dim3(T::NT), lds_bytes, st, b);
   DIF_HIP(hipGetLastError());
+  static const std::string label = kernel_label<T>("conv_bdp_kernel", AMP + 10);
+  g_last_kernel = label.c_str();
   return 0;
 }
 
@@ -2091,6 +2123,8 @@ static int launch_conv_pre_impl(const ConvArgs& a, hipStream_t st) {
   b.epi_fast = LEAN != 0;
   hipLaunchKernelGGL(kern, dim3((unsigned)P), dim3(T::NT), lds_bytes, st, b);
   DIF_HIP(hipGetLastError());
+  static const std::string label = kernel_label<T>(BF3 ? "conv_igemm_kernel[bf16x3]" : "conv_igemm_kernel", AM, PRE ? ",preact" : "");
+  g_last_kernel = label.c_str();
   return 0;
 }
 

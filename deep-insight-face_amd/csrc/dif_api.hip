@@ -101,16 +101,18 @@ int dif_gallery_set(dif_gallery* h, const float* rows_dev, int64_t n, int64_t in
     g.rows = g.rows2 = g.sq = g.ninv = nullptr;
     g.cap = 0;
     g.n = 0;                                               // an allocation failure below leaves an EMPTY gallery, not dangling rows
+    g.rows2_refused = false;
     DIF_HIP(hipMalloc(&g.rows, (size_t)n * g.d * sizeof(float)));
-    // the split-bf16 copy the filter reads: as large as the rows themselves; a gallery whose "filter" option was set to 0
-    // BEFORE its rows does without it (and keeps the f32 filter even if the option is switched back on later)
-    if (g.filter_bf2) DIF_HIP(hipMalloc(&g.rows2, (size_t)n * g.d * sizeof(float)));
     DIF_HIP(hipMalloc(&g.sq, (size_t)n * sizeof(float)));
     DIF_HIP(hipMalloc(&g.ninv, (size_t)n * sizeof(float)));
     g.cap = n;
+    // the split-bf16 copy the filter reads (as large as the rows themselves) is allocated by gallery_split_copy,
+    // from gallery_norms below or from the first dif_match after "filter" was switched on: NOT fatal when it does
+    // not fit -- the f32 filter needs no copy and gives the same answers
   }
   g.n = n;
   g.index_base = index_base;
+  g.rows2_valid = false;
   if (n == 0) return 0;
   DIF_HIP(hipMemcpyAsync(g.rows, rows_dev, (size_t)n * g.d * sizeof(float), hipMemcpyDeviceToDevice, st));
   return gallery_norms(&g, st);
@@ -125,10 +127,42 @@ int dif_gallery_set_option(dif_gallery* h, const char* key, int value) {
     return 0;
   }
   if (std::string(key) == "filter") {
-    h->g.filter_bf2 = value != 0;
+    Gallery& g = h->g;
+    g.filter_bf2 = value != 0;
+    if (!g.filter_bf2 && g.rows2) {            // the f32 filter reads the rows themselves: give the copy back
+      DIF_HIP(hipDeviceSynchronize());         // a dif_match in flight may still read it
+      DIF_HIP(hipFree(g.rows2));
+      g.rows2 = nullptr;
+      g.rows2_valid = false;
+    }
+    if (g.filter_bf2) g.rows2_refused = false; // switched (back) on: the next dif_gallery_set / dif_match builds the copy
     return 0;
   }
   return set_error("dif_gallery_set_option: unknown key '%s'", key);
+}
+
+int dif_gallery_get_stat(dif_gallery* h, const char* key, int64_t* out, void* stream) {
+  if (!h || !key || !out) return set_error("dif_gallery_get_stat: null argument");
+  Gallery& g = h->g;
+  const std::string k(key);
+  if (k == "split_copy") {
+    *out = (g.rows2 && g.rows2_valid) ? 1 : 0;
+    return 0;
+  }
+  if (k == "row_bytes") {                      // device bytes held per gallery row
+    *out = (int64_t)g.d * 4 * (g.rows2 ? 2 : 1) + 8;
+    return 0;
+  }
+  if (k == "exact_probes") {                   // probes the last dif_match sent to the exact whole-gallery search
+    int v = 0;
+    if (g.nflag) {
+      DIF_HIP(hipMemcpyAsync(&v, g.nflag, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+      DIF_HIP(hipStreamSynchronize((hipStream_t)stream));
+    }
+    *out = v;
+    return 0;
+  }
+  return set_error("dif_gallery_get_stat: unknown key '%s'", key);
 }
 
 int dif_match(dif_gallery* h, const float* probes_dev, int n, int metric, int64_t* idx_out_dev,

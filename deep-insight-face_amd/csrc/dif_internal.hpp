@@ -44,11 +44,14 @@ struct Gallery {
   int* nflag = nullptr;            // number of probes sent to the exact search in the current call
   unsigned* sqmax_bits = nullptr;  // bits of max |g|^2 over the rows the metric-0 filter sees
   struct GalleryFlags* flags = nullptr;   // rows the filter cannot rank (csrc/match.hip), found by gallery_norms
+  bool rows2_valid = false;        // rows2 holds the split of the CURRENT rows
+  bool rows2_refused = false;      // its allocation failed for this capacity: the f32 filter serves, no retry per call
   bool filter_bf2 = true;          // the MFMA filter runs on two-term split-bf16 operands (dif_gallery_set_option "filter" = 0: f32)
   bool clamp_nan = false;          // report distance 0 / 1 instead of the reference's NaN (dif_gallery_set_option)
 };
 
 int gallery_norms(Gallery* g, hipStream_t st);
+int gallery_split_copy(Gallery* g, hipStream_t st);   // (re)builds rows2 when the option asks for it; never fatal
 int match_run(Gallery* g, const float* probes, int B, int metric, int64_t* idx_out, float* dist_out,
               float* key_out, hipStream_t st);
 int pairwise_run(const float* e1, int64_t n1, const float* e2, int64_t n2, int D, int metric, float* out,

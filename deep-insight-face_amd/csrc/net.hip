@@ -897,6 +897,10 @@ int Net::set_option(const char* key, int value) {
       return set_error("dif_net_set_option: 'bf16x3' must be chosen before dif_net_finalize");
     return compute_bf16x3 = value != 0, 0;
   }
+  if (!strcmp(key, "lane_prio")) {
+    if (!pre) return set_error("dif_net_set_option: 'lane_prio' must be chosen before dif_net_finalize");
+    return opt_lane_prio = value, 0;
+  }
   if (!strcmp(key, "ysub") || !strcmp(key, "lane_split")) {
     if (!pre) return set_error("dif_net_set_option: '%s' must be chosen before dif_net_finalize", key);
     if (key[0] == 'y') use_ysub = value != 0;
@@ -1140,8 +1144,21 @@ int Net::finalize(int mb) {
   for (int l = 0; l < nl; ++l) {
     Lane& L = lanes[l];
     L.cap = l == 0 ? max_batch : (max_batch + nl - 1) / nl;   // lane 0 also serves unsplit and profiled forwards
-    if (l > 0) {
-      DIF_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+    if (l > 0 || (nl > 1 && opt_lane_prio == 0)) {
+      // A HIP stream is multiplexed onto one of a few hardware queues per PRIORITY level, the least referenced one.  A host
+      // framework that has filled the normal level before this net is finalized -- torch creates its whole stream pool with
+      // the first collective -- can leave this lane on the hardware queue of the caller's stream: the lanes then run one
+      // after the other and the forward is 5-18 % SLOWER than on one lane (measured: profiles/r04_rccl_lanes.txt).  A
+      // multi-lane forward therefore runs ALL its lanes on streams of the LEAST-priority level, which nothing else in the
+      // process uses -- lane 0 included, forked from and joined to the caller's stream by events, so the lanes compete as
+      // equals (option "lane_prio": 0 = that (default), 1 = lane 0 on the caller's stream, the others on normal-priority
+      // streams, as before round 4).
+      int prio_least = 0, prio_greatest = 0;
+      DIF_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+      if (opt_lane_prio == 0 && prio_least != prio_greatest)
+        DIF_HIP(hipStreamCreateWithPriority(&L.stream, hipStreamNonBlocking, prio_least));
+      else
+        DIF_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
       DIF_HIP(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
     }
     void* d = nullptr;
@@ -1182,7 +1199,11 @@ const char* Net::kernel_name(const Op& op, int n) const {
     case OP_ZERO: return "memset";
     case OP_UPSAMPLE: return "upsample2_kernel";
     case OP_COPY: return "copy_to_view_kernel";
-    case OP_CONV: return op.d_w_raw && use_stem ? (op.stem_mfma ? "stem_mfma_kernel" : "stem3x3_kernel") : "conv_igemm_kernel<64x64>";   // or its software-pipelined sibling conv_pipe_kernel (conv.hip)
+    case OP_CONV:
+      if (op.d_w_raw && use_stem) return op.stem_mfma ? "stem_mfma_kernel" : "stem3x3_kernel";
+      // the instantiation the op's last launch took (conv.hip: conv_igemm_kernel / conv_pipe_kernel / conv_bdp_kernel and
+      // their operand forms -- chosen per launch from the batch and the lane's grid); before any forward, the family
+      return op.ran_kernel && op.ran_kernel[0] ? op.ran_kernel : "conv_igemm_kernel<64x64>";
   }
   return "?";
 }
@@ -1303,6 +1324,7 @@ int Net::run_op(const Op& op, Lane& L, const void* xin, int n, int layout, int d
         break;
       }
       if (conv_run(a, st)) return -1;
+      op.ran_kernel = conv_last_kernel();
       break;
     }
     case OP_MAXPOOL: {
@@ -1440,19 +1462,20 @@ int Net::embed(const void* xin, int n, int layout, int dtype, float* out, hipStr
     if (l > 0 && c > lanes[l].cap) c = lanes[l].cap;     // cannot happen: cap = ceil(max_batch / nl)
     start[l + 1] = start[l] + c;
   }
+  const int l_first = lanes[0].stream ? 0 : 1;              // lane 0 has a stream of its own under "lane_prio" 0
   DIF_HIP(hipEventRecord(ev_start, st));
-  for (int l = 1; l < nl; ++l) DIF_HIP(hipStreamWaitEvent(lanes[l].stream, ev_start, 0));
+  for (int l = l_first; l < nl; ++l) DIF_HIP(hipStreamWaitEvent(lanes[l].stream, ev_start, 0));
   for (size_t i = 0; i < ops.size(); ++i) {
     for (int l = 0; l < nl; ++l) {
       const int c = start[l + 1] - start[l];
       if (c == 0) continue;
-      hipStream_t ls = l == 0 ? st : lanes[l].stream;
+      hipStream_t ls = lanes[l].stream ? lanes[l].stream : st;
       if (run_op(ops[i], lanes[l], static_cast<const char*>(xin) + (size_t)start[l] * in_bytes, c, layout, dtype,
                  out + (int64_t)start[l] * out_elems, ls))
         return -1;
     }
   }
-  for (int l = 1; l < nl; ++l) {
+  for (int l = l_first; l < nl; ++l) {
     DIF_HIP(hipEventRecord(lanes[l].done, lanes[l].stream));
     DIF_HIP(hipStreamWaitEvent(st, lanes[l].done, 0));
   }

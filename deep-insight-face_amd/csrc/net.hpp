@@ -81,6 +81,7 @@ struct Op {
   float* d_pre_shift = nullptr;
   int Kpad = 0;
   double macs = 0;   // per image
+  mutable const char* ran_kernel = nullptr;   // the conv kernel instantiation this op's last launch used (dif_net_op_info)
 };
 
 struct Net {
@@ -137,6 +138,7 @@ struct Net {
   int use_stem = 1;                 // option "stem": 0 runs 3-channel first layers on conv_igemm_kernel too
   int use_ysub = 1;                 // option "ysub" (before finalize): 0 keeps outputs read only at stride 2 dense
   int opt_lane_split = -1;          // option "lane_split" (before finalize): -1 by work per launch, 0 / 1 forced
+  int opt_lane_prio = 0;            // option "lane_prio" (before finalize): 0 = extra lanes on least-priority streams, 1 = normal
   int conv_dbg = 0;                 // option "dbg": ConvArgs::dbg
   unsigned conv_off = 0;            // options "patch", "patch2d", "bd" = 0: CONV_OFF_* bits handed to every convolution
   int set_option(const char* key, int value);   // dif_net_set_option; also applied from DIF_OPTIONS="key=value,..." at finalize

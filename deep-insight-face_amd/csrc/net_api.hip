@@ -140,6 +140,28 @@ int dif_net_op_info(const dif_net* h, int i, const char** name, const char** ker
   return 0;
 }
 
+int dif_net_op_traffic(const dif_net* h, int i, double* act_bytes_per_image, double* param_bytes) {
+  if (!h || i < 0 || i >= (int)h->net.ops.size()) return set_error("dif_net_op_traffic: index out of range");
+  const Net& net = h->net;
+  const Op& op = net.ops[i];
+  auto elems = [&](int t) -> double { return t >= 0 ? (double)net.tensors[t].elems() : 0.0; };
+  double rd = elems(op.x), wr = elems(op.y) + elems(op.y2), par = 0.0;
+  if (op.kind == OP_CONV) {
+    const TensorDesc& yd = net.tensors[op.y >= 0 ? op.y : op.y2];
+    // a strided 1x1 layer uses one input pixel per output pixel; every other layer its whole input
+    if (op.KH == 1 && op.KW == 1 && op.stride > 1 && op.x >= 0)
+      rd = (double)yd.H * yd.W * net.tensors[op.x].C;
+    if (op.y_sub && op.y >= 0) wr -= elems(op.y) * 0.75;          // first output kept at even pixels only
+    if (op.res >= 0) rd += (double)yd.H * yd.W * yd.C;
+    par = (double)op.KH * op.KW * op.Cin_true * op.Cout + 2.0 * op.Cout;
+  } else if (op.kind == OP_GDCTAIL || op.kind == OP_DWFULL || op.kind == OP_DWCONV) {
+    par = op.macs > 0 && op.kind == OP_GDCTAIL ? op.macs : 0.0;    // its three weight matrices = its MACs per image
+  }
+  if (act_bytes_per_image) *act_bytes_per_image = 4.0 * (rd + wr);
+  if (param_bytes) *param_bytes = 4.0 * par;
+  return 0;
+}
+
 int dif_net_embed_profile(dif_net* h, const void* x_dev, int n, int layout, int dtype, float* out_dev,
                           void* stream, float* ms_host) {
   if (!h || !ms_host) return set_error("dif_net_embed_profile: null argument");

@@ -105,6 +105,7 @@ struct ConvArgs {
 int conv_max_blocks();        // persistent blocks the kernel may use on this device
 size_t conv_slab_floats();    // floats per slab
 int conv_run(const ConvArgs& a, hipStream_t st);
+const char* conv_last_kernel();   // `family<tile, variant>` of the kernel this thread's last conv_run launched
 // which form of the split-bf16 kernel a 3x3 / stride 1 layer on an H x W map with Cout filters takes (0: none: f32 kernels)
 int conv_bf3p_form(int H, int W, bool batch_gt1, int Cout);
 

@@ -46,6 +46,7 @@ SIGNATURES = {
     'dif_gallery_set': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     'dif_gallery_size': (c_int64, [c_void_p]),
     'dif_gallery_set_option': (c_int, [c_void_p, c_char_p, c_int]),
+    'dif_gallery_get_stat': (c_int, [c_void_p, c_char_p, P(c_int64), c_void_p]),
     'dif_match': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dif_match_merge': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'dif_match_merge_packed': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
@@ -65,6 +66,7 @@ SIGNATURES = {
     'dif_net_flops_per_image': (c_double, [c_void_p]),
     'dif_net_launch_count': (c_int, [c_void_p]),
     'dif_net_op_info': (c_int, [c_void_p, c_int, P(c_char_p), P(c_char_p), P(c_double)]),
+    'dif_net_op_traffic': (c_int, [c_void_p, c_int, P(c_double), P(c_double)]),
     'dif_net_embed_profile': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, P(c_float)]),
     'dif_arcmargin_create': (c_int, [P(c_void_p), c_int, c_int64, c_float, c_float]),
     'dif_arcmargin_destroy': (c_int, [c_void_p]),

@@ -239,6 +239,16 @@ class DifEmbedder:
             rows.append((name.value.decode(), kern.value.decode(), macs.value))
         return rows
 
+    def op_traffic(self):
+        """Compulsory HBM bytes of every launch: (activation bytes per image, parameter bytes) -- the mixed roofline's
+        memory side (include/dif.h: dif_net_op_traffic)."""
+        rows = []
+        a, p = ctypes.c_double(), ctypes.c_double()
+        for i in range(N.lib.dif_net_launch_count(self._h)):
+            N.check(N.lib.dif_net_op_traffic(self._h, i, ctypes.byref(a), ctypes.byref(p)))
+            rows.append((a.value, p.value))
+        return rows
+
     def profile(self, x):
         """Per-launch milliseconds of one forward of a CUDA uint8/float batch (diagnostic):
         list of (op name, kernel name, MACs per image, ms)."""

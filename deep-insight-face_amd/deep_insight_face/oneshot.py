@@ -47,6 +47,14 @@ class Gallery:
         beyond +-1); the default 0 reports NaN like the reference.  The arg-min is unaffected."""
         N.check(N.lib.dif_gallery_set_option(self._h, key.encode(), int(value)), ValueError)
 
+    def stat(self, key):
+        """'split_copy': 1 when the filter's bf16 copy of the rows exists (it doubles the gallery's device memory;
+        when it cannot be allocated the float32 filter serves); 'row_bytes': device bytes per row;
+        'exact_probes': probes the last match sent to the exact whole-gallery search (synchronises)."""
+        v = ctypes.c_int64(0)
+        N.check(N.lib.dif_gallery_get_stat(self._h, key.encode(), ctypes.byref(v), N.stream_ptr()), ValueError)
+        return int(v.value)
+
     def match_into(self, probes, distance_metric, idx, dist, key=None):
         """Allocation-free form for a serving loop: `probes` [B, d] float32 CUDA, results written into the
         caller's CUDA tensors idx [B] int64, dist [B] float32 and (optional) key [B] float32 -- which may be

@@ -59,8 +59,16 @@ def _hip_merge(keys, idx, dists):
 class ShardedGallery:
     """Row shard of a gallery plus the two collectives around the local match."""
 
-    def __init__(self, shard_rows, index_base, group=None, match_fn=None, merge_fn=None, gallery=None):
+    def __init__(self, shard_rows, index_base, group=None, match_fn=None, merge_fn=None, gallery=None,
+                 force_collectives=False):
+        """`force_collectives`: with a world of ONE rank the two all-gathers and the merge are short-cut (they
+        would move a rank's data to itself); True runs them all the same -- the whole N > 1 branch over the real
+        backend on a single GPU (tests/test_parallel_gpu.py::test_rccl_single_rank_runs_the_sharded_branch).
+        Needs an initialised process group."""
         self.group = group
+        self.force = bool(force_collectives)
+        if self.force and not dist.is_initialized():
+            raise RuntimeError('force_collectives needs torch.distributed.init_process_group first')
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self._match = match_fn
@@ -76,7 +84,7 @@ class ShardedGallery:
 
     def all_gather_embeddings(self, local, out=None):
         """Step 2.  `local` is [b, d] on every rank (same b); returns [R*b, d]."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return local
         if out is None:
             out = torch.empty((self.world * local.shape[0], local.shape[1]), dtype=local.dtype, device=local.device)
@@ -106,7 +114,7 @@ class ShardedGallery:
         B = self.world * b
         probes = self.all_gather_embeddings(local_embeddings, buf.probes)
         k, dd, ix = buf.record(B)
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             self.gallery.match_into(probes, distance_metric, buf.out_idx, buf.out_dist)
         else:
             self.gallery.match_into(probes, distance_metric, ix, dd, k)
@@ -121,7 +129,7 @@ class ShardedGallery:
         """The same exchange with stand-in compute (CPU tests over gloo: the HIP kernels need a GPU)."""
         probes = self.all_gather_embeddings(local_embeddings)
         key, idx, d = self._match(self.gallery, probes, distance_metric)
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return idx, d
         B = probes.shape[0]
         rec = torch.cat([key.to(torch.float32), d.to(torch.float32), idx.to(torch.int64).view(torch.float32)])   # [4B]

@@ -120,11 +120,17 @@ int64_t dif_gallery_size(const dif_gallery* g);
 /* options.  "filter": 1 (default) the MFMA stage of dif_match -- a candidate filter with a proven error bound; the
  * winner is chosen on the reference's own float32 arithmetic either way -- runs on two-term split-bf16 copies of the
  * gallery and the probes (three bf16 MFMAs per 16 k), 0 on the f32 MFMA; results are identical.  The split copy of the
- * gallery doubles its device memory (d * 4 bytes per row more); set "filter" to 0 before dif_gallery_set to do without it.
+ * gallery doubles its device memory (d * 4 bytes per row more).  It is built by dif_gallery_set, or by the first
+ * dif_match after the option was switched on; setting "filter" to 0 frees it (in either order with dif_gallery_set);
+ * when it cannot be allocated the f32 filter serves and nothing fails (dif_gallery_get_stat "split_copy" tells).
  * "clamp_nan": 0 (default) dif_match reports NaN where the reference's distance is NaN; 1 reports the
  * distance of the similarity clamped to [-1, 1] instead (0 for a similarity rounded above 1, 1 below -1).  The
  * arg-min is the reference's either way. */
 int dif_gallery_set_option(dif_gallery* g, const char* key, int value);
+/* read-outs (no reference counterpart; for capacity planning and tests).  "split_copy": 1 when the filter's bf16 copy
+ * of the current rows exists; "row_bytes": device bytes held per gallery row; "exact_probes": how many probes the
+ * last dif_match on `stream` sent to the exact whole-gallery search (synchronises the stream). */
+int dif_gallery_get_stat(dif_gallery* g, const char* key, int64_t* out, void* stream);
 /* top-1 search of n probes [n][d]: idx_out_dev[n] = np.argmin over the reference's float32 distances
  * (int64 global index; first minimum; a row whose reference distance is NaN ranks first, as in
  * np.argmin: a similarity rounded beyond +-1, a zero-norm or non-finite gallery row or probe --
@@ -201,6 +207,11 @@ double dif_net_flops_per_image(const dif_net* net);
  * profiled forward synchronises the stream; it is a diagnostic, never the timed path. */
 int dif_net_launch_count(const dif_net* net);
 int dif_net_op_info(const dif_net* net, int i, const char** name, const char** kernel, double* macs_per_image);
+/* compulsory HBM traffic of op i for the mixed roofline (bench.py: t_roof = max(flops / MFMA peak, bytes / HBM rate) per
+ * launch): bytes of activations per image that the op must read (the input elements it uses, the shortcut) and write
+ * (its one or two outputs), and the bytes of its parameters (read once per launch whatever the batch).  `kernel` of
+ * dif_net_op_info is the instantiation the op's LAST launch ran (`family<tile, operand form>`), the family before. */
+int dif_net_op_traffic(const dif_net* net, int i, double* act_bytes_per_image, double* param_bytes);
 int dif_net_embed_profile(dif_net* net, const void* x_dev, int n, int layout, int dtype, float* out_dev,
                           void* stream, float* ms_host);
 

@@ -82,3 +82,42 @@ def test_shard_bounds_cover():
             assert all(edges[i][1] == edges[i + 1][0] for i in range(R - 1))
             sizes = [hi - lo for lo, hi in edges]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _force_worker(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from deep_insight_face.parallel import ShardedGallery
+        gal = gi.gallery(501, seed=3)
+        probes, _ = gi.probes_from(gal, 6, seed=4)
+        calls = {'n': 0}
+        orig = dist.all_gather_into_tensor
+
+        def counting(out, inp, group=None):
+            calls['n'] += 1
+            return orig(out, inp, group=group)
+
+        dist.all_gather_into_tensor = counting
+        res = {}
+        for force in (False, True):
+            calls['n'] = 0
+            sg = ShardedGallery(gal, 0, match_fn=_oracle_match, merge_fn=_cpu_merge, force_collectives=force)
+            idx, d = sg.match(torch.from_numpy(probes), 1)
+            res['idx%d' % force], res['d%d' % force], res['calls%d' % force] = idx.numpy(), d.numpy(), calls['n']
+        np.savez(os.path.join(out_dir, 'f.npz'), **res)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_force_collectives_world_of_one(tmp_path):
+    """A world of one rank short-cuts both all-gathers; force_collectives=True runs them (what the GPU suite
+    uses to put RCCL under the N > 1 branch on a single GPU).  Same answers either way."""
+    from deep_insight_face.parallel import ShardedGallery
+    with pytest.raises(RuntimeError, match='init_process_group'):
+        ShardedGallery(np.zeros((4, 8), np.float32), 0, match_fn=_oracle_match, force_collectives=True)
+    mp.spawn(_force_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    z = np.load(os.path.join(str(tmp_path), 'f.npz'))
+    assert int(z['calls0']) == 0 and int(z['calls1']) == 2
+    assert np.array_equal(z['idx0'], z['idx1']) and np.array_equal(z['d0'], z['d1'])

@@ -163,3 +163,29 @@ def test_single_rank_input_forms(cuda):
     with pytest.raises(ValueError):
         g.match_into(p_t, 1, oi, od_, key=od_.double())
     g.close()
+
+
+def test_rccl_single_rank_runs_the_sharded_branch(cuda, golden_dir, tmp_path):
+    """RCCL itself executes the N > 1 branch on the one GPU there is.  A FRESH child
+    process initialises backend "nccl" (= RCCL) with world_size 1 before any other GPU call and runs
+    ShardedGallery(force_collectives=True): all_gather_into_tensor of the embeddings -> dif_match into the
+    packed record -> the packed all-gather -> dif_match_merge_packed.  The answers must be the plain
+    Gallery.match's and the reference's (tests/golden/match_near_ties.npz)."""
+    import subprocess
+    import sys
+    out = os.path.join(str(tmp_path), 'rccl.npz')
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'rccl_single_rank_child.py')
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    r = subprocess.run([sys.executable, child, str(_free_port()), out], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    z = np.load(out)
+    g = np.load(os.path.join(golden_dir, 'match_near_ties.npz'))
+    assert str(z['backend']) == 'nccl' and int(z['world']) == 1
+    assert bool(z['gathered_equal']) and bool(z['copy_false_same_buffer'])
+    for m in (0, 1):
+        assert np.array_equal(z['idx%d' % m], g['idx%d' % m])
+        assert np.array_equal(z['idx%d' % m], z['plain_idx%d' % m])
+        assert np.array_equal(z['d%d' % m], z['plain_d%d' % m], equal_nan=True)
+    assert np.array_equal(z['idx_ragged'], g['idx1'][:5])
