@@ -126,6 +126,10 @@ int dif_gallery_set_option(dif_gallery* h, const char* key, int value) {
     h->g.clamp_nan = value != 0;
     return 0;
   }
+  if (std::string(key) == "bd") {
+    h->g.no_bd = value == 0;
+    return 0;
+  }
   if (std::string(key) == "filter") {
     Gallery& g = h->g;
     g.filter_bf2 = value != 0;
