@@ -126,6 +126,11 @@ int dif_gallery_set_option(dif_gallery* h, const char* key, int value) {
     h->g.clamp_nan = value != 0;
     return 0;
   }
+  if (std::string(key) == "bd_fill") {
+    if (value < 1 || value > 16) return set_error("dif_gallery_set_option: 'bd_fill' takes 1..16");
+    h->g.bd_fill = value;
+    return 0;
+  }
   if (std::string(key) == "bd") {
     h->g.no_bd = value == 0;
     return 0;

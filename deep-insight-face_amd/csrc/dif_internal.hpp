@@ -47,6 +47,7 @@ struct Gallery {
   bool rows2_valid = false;        // rows2 holds the split of the CURRENT rows
   bool rows2_refused = false;      // its allocation failed for this capacity: the f32 filter serves, no retry per call
   bool filter_bf2 = true;          // the MFMA filter runs on two-term split-bf16 operands (dif_gallery_set_option "filter" = 0: f32)
+  int bd_fill = 1;                 // "bd_fill": blocks of match_bd_kernel per resident slot (development: no effect measured, r04)
   bool no_bd = false;              // dif_gallery_set_option "bd" = 0: the split-bf16 filter stays on match_tile_kernel for every batch
   bool clamp_nan = false;          // report distance 0 / 1 instead of the reference's NaN (dif_gallery_set_option)
 };

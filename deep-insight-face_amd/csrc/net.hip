@@ -892,6 +892,10 @@ int Net::set_option(const char* key, int value) {
   if (!strcmp(key, "patch")) return flag(CONV_OFF_PATCH);
   if (!strcmp(key, "patch2d")) return flag(CONV_OFF_PATCH2D);
   if (!strcmp(key, "bd")) return flag(CONV_OFF_BD);
+  if (!strcmp(key, "pw")) {                                 // conv_pw_kernel is OFF by default: the bit means "on" for this family
+    conv_off = value ? (conv_off | CONV_OFF_PW) : (conv_off & ~CONV_OFF_PW);
+    return 0;
+  }
   if (!strcmp(key, "bf16x3")) {
     if (!pre && compute_bf16x3 != (value != 0))
       return set_error("dif_net_set_option: 'bf16x3' must be chosen before dif_net_finalize");
@@ -1000,8 +1004,11 @@ int Net::finalize(int mb) {
       // can take (3x3 / stride 1 / pad 1, whole 32-channel slices)
       op.d_w_frag = nullptr;
       op.w_frag_bytes = 0;
-      if (!op.d_w3f && op.k_order == 1 && op.KH == 3 && op.KW == 3 && op.stride == 1 && op.pad_t == 1 && op.pad_l == 1 &&
-          !op.pre_bn.valid()) {
+      // ... and every pointwise layer conv_pw_kernel can take (1x1 / stride 1, whole 64-channel K and column blocks)
+      const bool pw_layer = op.KH == 1 && op.KW == 1 && op.stride == 1 && op.pad_t == 0 && op.pad_l == 0 && op.Cin % 64 == 0 &&
+                            op.Cin_true == op.Cin && op.Cout % 64 == 0 && !op.chw_flatten;
+      if (pw_layer || (!op.d_w3f && op.k_order == 1 && op.KH == 3 && op.KW == 3 && op.stride == 1 && op.pad_t == 1 && op.pad_l == 1 &&
+          !op.pre_bn.valid())) {
         const int KS = op.Kpad / BK, NT32 = (op.Cout + 31) / 32;
         std::vector<float> frag((size_t)NT32 * 32 * op.Kpad, 0.f);
         size_t o = 0;

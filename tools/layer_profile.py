@@ -25,7 +25,7 @@ def main():
     rows2 = m.profile(x)
     tot_ms = tot_fl = 0.0
     agg = {}
-    print('%-28s %-24s %9s %8s %8s' % ('op', 'kernel', 'GFLOP', 'ms', 'TFLOP/s'))
+    print('%-28s %-44s %9s %8s %8s' % ('op', 'kernel', 'GFLOP', 'ms', 'TFLOP/s'))
     for (name, kern, macs, ms), (_, _, _, ms2) in zip(rows, rows2):
         ms = min(ms, ms2)
         fl = 2 * macs * B
@@ -35,10 +35,10 @@ def main():
         a[0] += ms
         a[1] += fl
         a[2] += 1
-        print('%-28s %-24s %9.2f %8.3f %8.1f' % (name, kern, fl / 1e9, ms, fl / ms / 1e9 if ms > 0 else 0))
+        print('%-28s %-44s %9.2f %8.3f %8.1f' % (name, kern, fl / 1e9, ms, fl / ms / 1e9 if ms > 0 else 0))
     print('TOTAL %.2f ms  %.1f TFLOP/s' % (tot_ms, tot_fl / tot_ms / 1e9))
     for k, (ms, fl, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
-        print('  %-24s launches %3d  %8.3f ms (%4.1f%%)  %6.1f TFLOP/s' % (k, n, ms, 100 * ms / tot_ms, fl / ms / 1e9))
+        print('  %-44s launches %3d  %8.3f ms (%4.1f%%)  %6.1f TFLOP/s' % (k, n, ms, 100 * ms / tot_ms, fl / ms / 1e9))
 
 
 if __name__ == '__main__':

@@ -14,6 +14,9 @@ gal = torch.nn.functional.normalize(torch.randn((G, 512), generator=g, device='c
 pick = torch.randperm(G, generator=g, device='cuda')[:B]
 probes = torch.nn.functional.normalize(gal[pick] + 0.03 * torch.randn((B, 512), generator=g, device='cuda'), dim=1)
 G_ = oneshot.Gallery(gal)
+for kv in os.environ.get('MATCH_OPTS', '').split(','):
+    if '=' in kv:
+        G_.set_option(kv.split('=')[0], int(kv.split('=')[1]))
 idx = torch.empty(B, dtype=torch.int64, device='cuda')
 dist = torch.empty(B, dtype=torch.float32, device='cuda')
 for _ in range(3):
@@ -24,4 +27,4 @@ for _ in range(reps):
     G_.match_into(probes, 1, idx, dist)
 ev[1].record()
 torch.cuda.synchronize()
-print('G=%d B=%d  %.3f ms per dif_match  ok=%s' % (G, B, ev[0].elapsed_time(ev[1]) / reps, bool(torch.equal(idx, pick))))
+print('G=%d B=%d %s %.3f ms per dif_match  ok=%s' % (G, B, os.environ.get('MATCH_OPTS', ''), ev[0].elapsed_time(ev[1]) / reps, bool(torch.equal(idx, pick))))
