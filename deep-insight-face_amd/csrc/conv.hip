@@ -41,6 +41,13 @@
 
 namespace dif {
 
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+
 // A-operand loader: gathers BM output pixels x 32 k-values per step.
 // KMODE 0: K layout decided at run time (any Cin % 4 == 0); KMODE 2: compile-time
 // specialisation for Cin % 32 == 0 with the channel-block-major K order (the 3x3 layers)
@@ -652,6 +659,7 @@ struct PatchDma {
     }
   }
   // staging (f32, slot-linear) -> the split planes; every thread converts the slots it fetched itself
+  template <int NPL = 3>
   __device__ __forceinline__ void convert(const char* staging, char* planes) const {
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));                          // as in issue(): recompute the slot addresses, do not keep them
@@ -665,7 +673,7 @@ struct PatchDma {
         char* w = planes + (slot >> 3) * BF3P_EB + (slot & 7) * 8;
         *reinterpret_cast<u32x2*>(w) = hi;
         *reinterpret_cast<u32x2*>(w + 64) = mid;
-        *reinterpret_cast<u32x2*>(w + 128) = lo;
+        if constexpr (NPL == 3) *reinterpret_cast<u32x2*>(w + 128) = lo;
       }
     }
   }
@@ -723,6 +731,7 @@ struct PatchDma2D {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, lds_ptr_of(staging + (wave * 64 + T::NT * j) * 16), 16, off, 0, 0, 0);
     }
   }
+  template <int NPL = 3>
   __device__ __forceinline__ void convert(const char* staging, char* planes) const {
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
@@ -736,7 +745,7 @@ struct PatchDma2D {
         char* w = planes + (slot >> 3) * BF3P_EB + (slot & 7) * 8;
         *reinterpret_cast<u32x2*>(w) = hi;
         *reinterpret_cast<u32x2*>(w + 64) = mid;
-        *reinterpret_cast<u32x2*>(w + 128) = lo;
+        if constexpr (NPL == 3) *reinterpret_cast<u32x2*>(w + 128) = lo;
       }
     }
   }
@@ -750,127 +759,29 @@ struct PatchDma2D {
 //   A fragments: two sets, read one sub-step ahead;
 //   the patch:   the next slice's f32 patch arrives by LDS-DMA under taps 4..8 and is split into the planes at the slice
 //                boundary, between two LDS-only barriers (the B ring stays in flight).
+// NPL = 3: six products (hi + mid + lo, "bf16x3"); NPL = 2: the two-term tier ("bf16x2": hi + mid, three products mid.hi,
+// hi.mid, hi.hi -- half the MFMAs and two thirds of the B bytes; the lo plane is neither written nor read)
+// The mainloop itself lives in conv_bf_mainloop.hpp, included once per number of bf16 terms (3: six products, "bf16x3";
+// 2: hi + mid only, three products -- half the MFMAs, two thirds of the B bytes -- "bf16x2").
+#define BF_NPL_VALUE 3
+#define BF_MAINLOOP_NAME gemm_mainloop_patch_bf3
+#include "conv_bf_mainloop.hpp"
+#undef BF_NPL_VALUE
+#undef BF_MAINLOOP_NAME
+#define BF_NPL_VALUE 2
+#define BF_MAINLOOP_NAME gemm_mainloop_patch_bf2t
+#include "conv_bf_mainloop.hpp"
+#undef BF_NPL_VALUE
+#undef BF_MAINLOOP_NAME
+// Both live in every split-bf16 kernel; ConvArgs::bf_terms (launch-invariant, block-uniform) picks one per mainloop call.
+// (Compile-time selection was tried in four forms -- a template parameter of the function, of a wrapping class, a tag argument,
+// a property of the loader type, `if constexpr` at the call: the HOST pass of this compiler rejected each with a reasonless
+// "substitution failure" at the call inside the kernel's `run` lambda, while the device pass accepted all of them.)
 template <class T, class PA>
-__device__ __forceinline__ void gemm_mainloop_patch_bf3(const PA& pa, const ConvArgs& a, int n0, int cbeg, int cend,
-                                                        char* lds, f32x16 (&acc)[T::WM][T::WN]) {
-  constexpr int WM = T::WM, WN = T::WN;
-  static_assert((WM == 2 && (WN == 1 || WN == 2)) || (WM == 4 && WN == 1), "split-bf16 patch path: wave tiles 64 x 64, 64 x 32, 128 x 32");
-  const int lane = threadIdx.x & 63, h = lane >> 5;
-  const int KS = a.Kpad / BK;
-  char* staging = lds + bf3p_planes_b(T::BM);
-  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.w3f, a.w3f_bytes);
-  uint32_t boff[WN];
-#pragma unroll
-  for (int n = 0; n < WN; ++n)
-    boff[n] = (uint32_t)((n0 >> 5) + T::wave_col() * WN + n) * (uint32_t)KS * (uint32_t)BF3P_KSTEP_B + (uint32_t)lane * 16u;
-  const int klast = 9 * cend - 1;
-  // sub-step index u = 2 * K-step + half; past the range the last K-step is fetched again (branch-free, never used)
-  auto bload = [&](int u, u32x4 (&b)[WN][3]) {
-    // (no run-time condition around these loads: at a join behind a skipped load group the compiler must assume the
-    // FEWEST younger loads, i.e. wait for vmcnt(0), and the ring's lookahead is gone)
-    int ks = u >> 1;
-    ks = ks < klast ? ks : klast;
-    const uint32_t so = (uint32_t)ks * (uint32_t)BF3P_KSTEP_B + (uint32_t)(u & 1) * 3072u;
-#pragma unroll
-    for (int n = 0; n < WN; ++n)
-#pragma unroll
-      for (int p = 0; p < 3; ++p) b[n][p] = __builtin_amdgcn_raw_buffer_load_b128(wrs, boff[n], so + (uint32_t)p * 1024u, 0);
-  };
-  uint32_t arow[WM];                                        // byte address of (this lane's pixel, tap row kh, kw = 0), per m
-  auto aread = [&](int kw, int s, u32x4 (&f)[WM][3]) {
-#pragma unroll
-    for (int m = 0; m < WM; ++m)
-#pragma unroll
-      for (int p = 0; p < 3; ++p)
-        f[m][p] = *reinterpret_cast<const u32x4*>(lds + arow[m] + kw * BF3P_EB + p * 64 + s * 32);
-  };
-  // lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi (small terms first); the four accumulators take turns
-  auto mfma24 = [&](const u32x4 (&fa)[WM][3], const u32x4 (&fb)[WN][3]) {
-    constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-    for (int q = 0; q < 6; ++q)
-#pragma unroll
-      for (int m = 0; m < WM; ++m)
-#pragma unroll
-        for (int n = 0; n < WN; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[m][QA[q]]),
-                                                              __builtin_bit_cast(bf16x8, fb[n][QB[q]]), acc[m][n], 0, 0, 0);
-  };
-  auto set_row = [&](int kh) {
-#pragma unroll
-    for (int m = 0; m < WM; ++m) arow[m] = (uint32_t)(pa.base[m] + kh * pa.WP) * (uint32_t)BF3P_EB + (uint32_t)h * 16u;
-  };
-
-  // B fragments: a ring of RING sub-step sets requested RING - 1 sub-steps ahead (18 % RING == 0 keeps the ring's phase fixed
-  // per slice); A fragments: FA_SETS sets (2 = read one sub-step ahead, 1 = right before their MFMAs).
-  // What the loop is bound by (profiles/r03_ablation.txt): with real operands a K-step takes 2.0-2.1 us against 1.34 us of
-  // matrix-pipe time, and NOTHING about the operand streams moves it -- half the B bytes per MFMA (256-row blocks), half the B
-  // loads per wave (128 x 32 wave tiles), a ring of six sets (2.5 K-steps ahead), accumulators in AccVGPRs.  With all-zero
-  // WEIGHTS -- same instructions, same loads, same bytes -- it runs 20 % faster and the clock held inside the kernels goes from
-  // 2.06 to 2.38 GHz: six bf16 MFMAs per product on random data are limited by board power, not by this loop's structure.
-  constexpr int RING = WN == 1 ? 6 : 3, LOOK = RING - 1;
-  constexpr int FA_SETS = WM == 4 ? 1 : 2;
-  static_assert(18 % RING == 0, "ring phase");
-  u32x4 bq[RING][WN][3];
-  u32x4 fa[FA_SETS][WM][3];
-  pa.issue(cbeg, staging);
-#pragma unroll
-  for (int i = 0; i < LOOK; ++i) bload(18 * cbeg + i, bq[i]);
-  // the patch has landed (the LOOK * 3 * WN B loads behind it may be in flight)
-  if constexpr (LOOK * 3 * WN == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  else if constexpr (LOOK * 3 * WN == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  pa.convert(staging, lds);
-  lds_barrier();
-  for (int cb = cbeg; cb < cend; ++cb) {
-    const int u0 = 18 * cb;
-    set_row(0);
-    if constexpr (FA_SETS == 2) aread(0, 0, fa[0]);
-    // sub-step I of the slice (compile time): tap I / 2, half I % 2
-    auto substep = [&](auto ic) {
-      constexpr int I = decltype(ic)::value;
-      constexpr int N = FA_SETS == 2 ? I + 1 : I, ntap = N / 2;   // the sub-step whose A fragments are read now
-      if constexpr (N < 18) {
-        if constexpr (N % 6 == 0 && N > 0) set_row(ntap / 3);     // next tap row
-        aread(ntap % 3, N & 1, fa[N % FA_SETS]);
-      }
-      bload(u0 + I + LOOK, bq[(I + LOOK) % RING]);
-      if constexpr (I == 2 * PATCH_PF_TAP) {
-        if (cb + 1 < cend) pa.issue(cb + 1, staging);      // lands while the remaining taps run
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      mfma24(fa[I % FA_SETS], bq[I % RING]);
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    substep(std::integral_constant<int, 0>());
-    substep(std::integral_constant<int, 1>());
-    substep(std::integral_constant<int, 2>());
-    substep(std::integral_constant<int, 3>());
-    substep(std::integral_constant<int, 4>());
-    substep(std::integral_constant<int, 5>());
-    substep(std::integral_constant<int, 6>());
-    substep(std::integral_constant<int, 7>());
-    substep(std::integral_constant<int, 8>());
-    substep(std::integral_constant<int, 9>());
-    substep(std::integral_constant<int, 10>());
-    substep(std::integral_constant<int, 11>());
-    substep(std::integral_constant<int, 12>());
-    substep(std::integral_constant<int, 13>());
-    substep(std::integral_constant<int, 14>());
-    substep(std::integral_constant<int, 15>());
-    substep(std::integral_constant<int, 16>());
-    substep(std::integral_constant<int, 17>());
-    if (cb + 1 < cend) {
-      // this thread's share of the next patch is in LDS (everything but the ring's youngest loads has landed)
-      if constexpr (LOOK * 3 * WN == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      else if constexpr (LOOK * 3 * WN == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      lds_barrier();                                       // every wave has read its last fragment of the old patch
-      pa.convert(staging, lds);
-      lds_barrier();
-    }
-  }
-  lds_barrier();
+__device__ __forceinline__ void gemm_mainloop_patch_bf(const PA& pa, const ConvArgs& a, int n0, int cbeg, int cend, char* lds,
+                                                       f32x16 (&acc)[T::WM][T::WN]) {
+  if (a.bf_terms == 2) gemm_mainloop_patch_bf2t<T>(pa, a, n0, cbeg, cend, lds, acc);
+  else gemm_mainloop_patch_bf3<T>(pa, a, n0, cbeg, cend, lds, acc);
 }
 
 __device__ __forceinline__ float apply_act(float v, int act, float alpha) {
@@ -1144,7 +1055,7 @@ struct NoLoader {};   // B operand of the B-direct kernels: fetched by the mainl
 // BF3 (with AM = 13): the split-bf16 patch kernel, gemm_mainloop_patch_bf3 on the fragment-order split weights a.w3f
 // LEAN: the tile is finished by conv_epilogue_fast (the launcher checked its case), otherwise by the general conv_epilogue --
 // one of the two per instantiation, not both behind a run-time flag
-template <class T, bool PRE, int AM, bool BF3 = false, int LEAN = 0>   // LEAN: 0 general, 1 lean, 2 lean + sub-sampled first output
+template <class T, bool PRE, int AM, int BF3 = 0, int LEAN = 0>   // LEAN: 0 general, 1 lean, 2 lean + sub-sampled first output
 __global__ __launch_bounds__(T::NT, (BF3 ? 2 : T::MIN_BLOCKS)) void conv_igemm_kernel(const ConvArgs a) {
   static_assert(!BF3 || ((AM == 13 || AM == 16) && !PRE), "split-bf16 exists as the B-direct patch kernel only");
   constexpr int AMP = AM % 10;                              // AM >= 10: the B-direct form of patch path AM - 10
@@ -1208,7 +1119,7 @@ __global__ __launch_bounds__(T::NT, (BF3 ? 2 : T::MIN_BLOCKS)) void conv_igemm_k
     EpiRes<T> er;
     auto run = [&](int k0, int k1, bool prefetch_res) {
       if constexpr (B3P)
-        gemm_mainloop_patch_bf3<T>(al, a, n0, k0, k1, reinterpret_cast<char*>(smem), acc);
+        gemm_mainloop_patch_bf<T>(al, a, n0, k0, k1, reinterpret_cast<char*>(smem), acc);
       else if constexpr (BD)
         gemm_mainloop_patch_bd<T>(al, a, n0, k0, k1, smem, acc, [&] {
           if (prefetch_res && a.res) er.load(a, m0, n0);
@@ -1858,7 +1769,7 @@ static std::string kernel_label(const char* family, int am, const char* extra = 
 size_t conv_slab_floats() { return 128 * 128; }   // per resident slot (sk_max_blocks of them): published partial + fallback stash of
                                                    // either shipped tile -- 1024 x 2 x 64x64 or 512 x 2 x 128x128 floats, 64 MiB per lane
 
-template <class T, bool PRE, int AM, bool BF3 = false>
+template <class T, bool PRE, int AM, int BF3 = 0>
 static int launch_conv_pre(const ConvArgs& a, hipStream_t st);
 
 // Short K loop, several whole tiles per resident block, plain output, unit-stride shortcut: the
@@ -2046,12 +1957,6 @@ struct PwTile {
   // behind them and the B sets of the sub-steps in between -- in the loop 4 LA WN loads, at the first step the prologue's 2 LB WN
   static constexpr int VMCNT = 4 * LA + (4 * LA * WN < 2 * LB * WN ? 4 * LA * WN : 2 * LB * WN);
 };
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 
 template <class T, bool PRE>
 __global__ __launch_bounds__(T::NT, T::OCC * T::NW / 4) void conv_pw_kernel(const ConvArgs a, int tiles_n, int ntiles) {
@@ -2363,10 +2268,10 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
   return launch_conv_pre<T, false, 0>(a, st);
 }
 
-template <class T, bool PRE, int AM, bool BF3, int LEAN>
+template <class T, bool PRE, int AM, int BF3, int LEAN>
 static int launch_conv_pre_impl(const ConvArgs& a, hipStream_t st);
 
-template <class T, bool PRE, int AM, bool BF3>
+template <class T, bool PRE, int AM, int BF3>
 static int launch_conv_pre(const ConvArgs& a, hipStream_t st) {
   // the lean epilogue's case (conv_epilogue_fast)
   const bool lean = !(a.dbg & 1024) && a.y_H == a.Ho && a.y_W == a.Wo && a.y_oy == 0 && a.y_ox == 0 && a.y_ld == a.Cout &&
@@ -2376,7 +2281,7 @@ static int launch_conv_pre(const ConvArgs& a, hipStream_t st) {
   else return lean ? launch_conv_pre_impl<T, PRE, AM, BF3, 1>(a, st) : launch_conv_pre_impl<T, PRE, AM, BF3, 0>(a, st);
 }
 
-template <class T, bool PRE, int AM, bool BF3, int LEAN>
+template <class T, bool PRE, int AM, int BF3, int LEAN>
 static int launch_conv_pre_impl(const ConvArgs& a, hipStream_t st) {
   auto kern = conv_igemm_kernel<T, PRE, AM, BF3, LEAN>;
   constexpr int AMP = AM % 10;
@@ -2423,7 +2328,7 @@ static int launch_conv_pre_impl(const ConvArgs& a, hipStream_t st) {
   b.epi_fast = LEAN != 0;
   hipLaunchKernelGGL(kern, dim3((unsigned)P), dim3(T::NT), lds_bytes, st, b);
   DIF_HIP(hipGetLastError());
-  static const std::string label = kernel_label<T>(BF3 ? "conv_igemm_kernel[bf16x3]" : "conv_igemm_kernel", AM, PRE ? ",preact" : "");
+  static const std::string label = kernel_label<T>(BF3 ? "conv_igemm_kernel[split-bf16]" : "conv_igemm_kernel", AM, PRE ? ",preact" : "");
   g_last_kernel = label.c_str();
   return 0;
 }
@@ -2455,11 +2360,13 @@ int conv_run(const ConvArgs& a, hipStream_t st) {
   }
   // (four waves of 128 x 32 with a six-set B ring, and eight waves on a 256 x 128 tile -- Tile<4, 1, 1, 4>, Tile<2, 2, 4, 2>: the
   // mainloop takes either -- measured the same as this one within 2 %)
-  switch (bf3p_applies(a) * 2 + (a.Cout <= 64 ? 1 : 0)) {
-    case 2: return launch_conv_pre<Tile<2, 2, 2, 2>, false, 13, true>(a, st);     // linear patch, 128 columns
-    case 3: return launch_conv_pre<Tile<2, 1, 2, 2>, false, 13, true>(a, st);     // linear patch, 64 columns
-    case 4: return launch_conv_pre<Tile<2, 2, 2, 2>, false, 16, true>(a, st);     // two 8x8 sub-tiles, 128 columns
-    case 5: return launch_conv_pre<Tile<2, 1, 2, 2>, false, 16, true>(a, st);     // two 8x8 sub-tiles, 64 columns
+  // (three or two bf16 terms per operand: ConvArgs::bf_terms, picked inside the kernel)
+  const int form = bf3p_applies(a) * 2 + (a.Cout <= 64 ? 1 : 0);
+  switch (form) {
+    case 2: return launch_conv_pre<Tile<2, 2, 2, 2>, false, 13, 1>(a, st);     // linear patch, 128 columns
+    case 3: return launch_conv_pre<Tile<2, 1, 2, 2>, false, 13, 1>(a, st);     // linear patch, 64 columns
+    case 4: return launch_conv_pre<Tile<2, 2, 2, 2>, false, 16, 1>(a, st);     // two 8x8 sub-tiles, 128 columns
+    case 5: return launch_conv_pre<Tile<2, 1, 2, 2>, false, 16, 1>(a, st);     // two 8x8 sub-tiles, 64 columns
     default: break;
   }
   return launch_conv<Tile<1, 1>>(a, st);

@@ -901,6 +901,10 @@ int Net::set_option(const char* key, int value) {
       return set_error("dif_net_set_option: 'bf16x3' must be chosen before dif_net_finalize");
     return compute_bf16x3 = value != 0, 0;
   }
+  if (!strcmp(key, "bf_terms")) {                          // 3 or 2 bf16 terms per operand in the split-bf16 mode (any time)
+    if (value != 2 && value != 3) return set_error("dif_net_set_option: 'bf_terms' takes 2 or 3");
+    return bf_terms = value, 0;
+  }
   if (!strcmp(key, "lane_prio")) {
     if (!pre) return set_error("dif_net_set_option: 'lane_prio' must be chosen before dif_net_finalize");
     return opt_lane_prio = value, 0;
@@ -1251,6 +1255,7 @@ int Net::run_op(const Op& op, Lane& L, const void* xin, int n, int layout, int d
       a.w3f_bytes = op.w3f_bytes;
       a.w_frag = op.d_w_frag;
       a.w_frag_bytes = op.w_frag_bytes;
+      a.bf_terms = bf_terms;
       a.y = ptr(op.y);
       a.y2 = ptr(op.y2);
       a.scale = op.d_scale;

@@ -132,6 +132,7 @@ struct Net {
   std::vector<int64_t> buf_elems;   // per image
   int sk_max_blocks = 0;
   int sk_spin_limit = 1 << 18;
+  int bf_terms = 3;                 // option "bf_terms": 3 = bf16x3 (six products), 2 = bf16x2 (hi + mid, three products)
   int compute_bf16x3 = 0;           // option "bf16x3" (set before finalize): convolutions on the split-bf16 MFMA path
   int use_pipe = 1;                 // option "pipe": 0 keeps every convolution on conv_igemm_kernel
   int use_bdp = 1;                  // option "bdp": 0 never conv_bdp_kernel, 1 where it pays, 2 wherever it can run

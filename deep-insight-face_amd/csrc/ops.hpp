@@ -48,6 +48,7 @@ struct ConvArgs {
   uint32_t w_frag_bytes;
   const void* w3f;      // split-bf16 mode, 3x3 / stride 1 layers: the three bf16 planes in MFMA-fragment order (conv.hip:
   uint32_t w3f_bytes;   // gemm_mainloop_patch_bf3), [ceil(Cout/32)][Kpad/32][s 2][plane 3][lane 64][8]
+  int bf_terms;         // 3 (or 0): all three planes, six products; 2: the hi and mid planes only, three products ("bf16x2")
   int k_order;          // 0: k = (kh*KW + kw)*Cin + ci (tap-major)
                         // 1: k = ((ci/32)*KH*KW + kh*KW + kw)*32 + ci%32 (channel-block-major, Cin % 32 == 0):
                         //    consecutive K-steps sweep the taps of ONE 32-channel slice, i.e. re-read the

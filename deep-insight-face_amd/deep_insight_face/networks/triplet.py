@@ -32,11 +32,13 @@ class DifEmbedder:
         N.check(N.lib.dif_net_create(ctypes.byref(self._h), arch.encode(), head.encode(), self.emd_size,
                                      self.input_shape[0], self.input_shape[1]), ValueError)
         self._ready = False
-        if compute not in ('f32', 'bf16x3'):
-            raise ValueError("compute must be 'f32' (the reference's arithmetic) or 'bf16x3' (split-bf16 throughput mode)")
+        if compute not in ('f32', 'bf16x3', 'bf16x2'):
+            raise ValueError("compute must be 'f32' (the reference's arithmetic), 'bf16x3' (split-bf16 throughput mode: three "
+                             "bf16 terms per operand, six products) or 'bf16x2' (two terms, three products)")
         self.compute = compute
-        if compute == 'bf16x3':
+        if compute in ('bf16x3', 'bf16x2'):
             N.check(N.lib.dif_net_set_option(self._h, b'bf16x3', 1), ValueError)
+            N.check(N.lib.dif_net_set_option(self._h, b'bf_terms', 3 if compute == 'bf16x3' else 2), ValueError)
         shp = (ctypes.c_int64 * 3)()
         N.check(N.lib.dif_net_output_dim(self._h, shp))
         c, h, w = int(shp[0]), int(shp[1]), int(shp[2])

@@ -442,16 +442,17 @@ def test_embed_full_batch_properties(cuda):
                                              ('iresnet100', 'v2', 512, 64),
                                              ('resnet', 'v2', 512, 512), ('resnet', 'v1', 128, 512),
                                              ('vgg16', 'v2', 512, 16)])
-def test_embed_bf16x3_mode_vs_oracle(cuda, arch, head, emd, n):
-    """The split-bf16 throughput mode (dif_net_set_option "bf16x3": three bf16 terms per f32 operand, six MFMA
-    products, f32 accumulation) against the float32 path on the whole batch and against the oracle on spot rows,
-    at the same gates: cosine gap < 1e-5 (oracle) / 1e-6 (f32 path), pairwise cosine distances within 1e-5.
+@pytest.mark.parametrize('compute', ['bf16x3', 'bf16x2'])
+def test_embed_bf16x3_mode_vs_oracle(cuda, arch, head, emd, n, compute):
+    """The split-bf16 throughput modes -- "bf16x3": three bf16 terms per f32 operand, six MFMA products; "bf16x2" (round 4):
+    two terms, three products -- f32 accumulation, against the float32 path on the whole batch and against the oracle on
+    spot rows, at the same gates: cosine gap < 1e-5 (oracle) / 1e-6 (f32 path), pairwise cosine distances within 1e-5.
     The batches are large enough for the mode to engage (conv.hip: bf3_pays -- short or small layers stay on
     the f32 kernels), including the halo-patch 3x3 path; `launches` below checks that it did."""
     from deep_insight_face.networks.triplet import DifEmbedder
     u8 = crops_u8(n, seed=31)
     f32 = DifEmbedder(arch, head, emd, (112, 112, 3), max_batch=n).init_synthetic(2024)
-    b3 = DifEmbedder(arch, head, emd, (112, 112, 3), max_batch=n, compute='bf16x3')
+    b3 = DifEmbedder(arch, head, emd, (112, 112, 3), max_batch=n, compute=compute)
     p = f32.get_weights()
     b3.set_weights(p)
     for m in (f32, b3):

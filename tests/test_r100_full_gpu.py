@@ -178,8 +178,9 @@ def test_odd_sizes_pipelined_vs_plain_vs_oracle(cuda, monkeypatch, arch, head, e
 
 
 @pytest.mark.parametrize('batch', [256, 512])
-def test_iresnet100_full_batch_bf16x3(r100, batch):
-    """The split-bf16 throughput mode (conv.hip: gemm_mainloop_patch_bf3, the B-direct halo-patch kernel on 128 x 128 tiles
+@pytest.mark.parametrize('compute', ['bf16x3', 'bf16x2'])
+def test_iresnet100_full_batch_bf16x3(r100, batch, compute):
+    """The split-bf16 throughput modes ("bf16x3": six products; "bf16x2": hi + mid, three products) (conv.hip: gemm_mainloop_patch_bf3, the B-direct halo-patch kernel on 128 x 128 tiles
     with the stream-K grid cut at slice boundaries) at the benchmarked sizes and under the default executor: against the
     float32 path of the same weights on the whole batch (cosine gap < 1e-6), against the oracle on spot rows of both lanes
     (gap < 1e-5, pairwise cosine distances within 1e-5), finite, unit norm, deterministic, and on a gallery built from the
@@ -187,7 +188,7 @@ def test_iresnet100_full_batch_bf16x3(r100, batch):
     from deep_insight_face import oneshot
     from deep_insight_face.networks.triplet import DifEmbedder
     model, p = r100
-    b3 = DifEmbedder('iresnet100', 'v2', 512, (112, 112, 3), max_batch=512, compute='bf16x3')
+    b3 = DifEmbedder('iresnet100', 'v2', 512, (112, 112, 3), max_batch=512, compute=compute)
     b3.set_weights(p)
     b3.set_input_transform(scale=1 / 255.)
     u8 = crops_u8(batch, seed=5200 + batch)
