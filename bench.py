@@ -51,6 +51,10 @@ WORKLOADS = {
                        'configs[3] shape in the split-bf16 THROUGHPUT mode (not the headline: the headline is float32, the '
                        'reference\'s arithmetic): every f32 operand as three bf16 terms, six bf16 MFMA products, f32 '
                        'accumulation; same 1e-5 cosine parity gate'),
+    'r100_1m_bf16x2': ('iresnet100', 'v2', 512, 1_000_000,
+                       'configs[3] shape in the two-term split-bf16 THROUGHPUT mode (not the headline): every f32 operand as hi + mid '
+                       'in bf16, three bf16 MFMA products, f32 accumulation; passes the float32 gates (cosine gap < 1e-5, pairwise '
+                       'distances within 1e-5, same gallery rows)'),
     'frames': ('resnet', 'v2', 256, 100_000,
                'configs[4]: 256 raw 640x480 frames/GPU -> letterbox -> YOLOv3-face -> best box -> crop 112 -> '
                'ResNet-50V2 embed -> 100k gallery match (the reference ships YOLOv3-face, not MTCNN)'),
@@ -391,7 +395,7 @@ def main():
     from deep_insight_face.parallel import ShardedGallery, shard_bounds
 
     arch, head, batch, gallery_rows, desc = WORKLOADS[args.workload]
-    compute = 'bf16x3' if args.workload.endswith('_bf16x3') else 'f32'
+    compute = 'bf16x3' if args.workload.endswith('_bf16x3') else ('bf16x2' if args.workload.endswith('_bf16x2') else 'f32')
     batch = args.batch or batch
     gallery_rows = args.gallery or gallery_rows
 
@@ -569,7 +573,9 @@ def main():
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
-            'dtype': 'f32' if compute == 'f32' else 'bf16x3 (f32 operands split into 3 bf16 terms, 6 MFMA products, f32 accumulate)',
+            'dtype': 'f32' if compute == 'f32' else ('bf16x3 (f32 operands split into 3 bf16 terms, 6 MFMA products, f32 accumulate)'
+                                                     if compute == 'bf16x3' else
+                                                     'bf16x2 (f32 operands split into 2 bf16 terms, 3 MFMA products, f32 accumulate)'),
             'data': 'synthetic (uint8 crops seed 1234, He-normal weights seed 2024, unit-norm gallery seed 7)',
             'verified': verified,       # after the timed region: 8 planted enrolments found at their rows by one more step
             # what carried the collectives: under backend "nccl" (= RCCL on ROCm) rccl_ranks is the size of the communicator
@@ -621,13 +627,14 @@ def main():
                              'note': '(t_roof of the embedding forward at the f32-MFMA peak + t_roof of the match) / measured step'},
             },
         }
-        if compute == 'bf16x3':
-            # honest denominators: the bf16 MFMA peak, against which 6 MFMA flops are spent per algorithmic flop
+        if compute != 'f32':
+            # honest denominators: the bf16 MFMA peak, against which 6 (3) MFMA flops are spent per algorithmic flop
+            nprod = 6.0 if compute == 'bf16x3' else 3.0
             out['roofline']['peak_note'] = ('frac above is against the f32-MFMA peak for comparison with the float32 path; the '
-                                            'mode runs on the bf16 MFMA (2500 TFLOP/s dense), 6 products per algorithmic '
-                                            'multiply-add: ceiling 2500/6 = 416.7 TFLOP/s algorithmic')
-            out['roofline']['frac_of_bf16x3_ceiling'] = achieved / (2500.0 / 6.0)
-            out['roofline']['bf16_mfma_tflops_issued'] = achieved * 6.0
+                                            'mode runs on the bf16 MFMA (2500 TFLOP/s dense), %d products per algorithmic '
+                                            'multiply-add: ceiling 2500/%d = %.1f TFLOP/s algorithmic' % (nprod, nprod, 2500.0 / nprod))
+            out['roofline']['frac_of_%s_ceiling' % compute] = achieved / (2500.0 / nprod)
+            out['roofline']['bf16_mfma_tflops_issued'] = achieved * nprod
         if b256_ms is not None:
             a256 = model.flops_per_image * 256 / (b256_ms * 1e-3) / 1e12
             out['roofline']['b256'] = {'forward_ms_hip_events': b256_ms, 'achieved': a256, 'peak': PEAK_F32_MFMA_TFLOPS,

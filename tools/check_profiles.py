@@ -1,4 +1,4 @@
-"""Copies the round-3 rocprofv3 summaries from gpurun_out/r03/ into profiles/ and prints the cross-checks
+"""Copies the round's rocprofv3 summaries from gpurun_out/r04/ into profiles/ and prints the cross-checks
 the bench line's `roofline` rests on: per forward, the sum of the conv kernel durations in the kernel-trace stats
 (one lane: no overlap) vs the HIP-event forward time reported by bench.py, and the frac recomputed from them."""
 import csv
@@ -9,9 +9,9 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, 'gpurun_out', 'r03')
+OUT = os.path.join(ROOT, 'gpurun_out', 'r04')
 PROF = os.path.join(ROOT, 'profiles')
-R = 'r03'
+R = 'r04'
 PEAK = 157.3
 
 
@@ -48,19 +48,19 @@ def main():
     cp('ks_default_1lane/p_kernel_stats.csv', R + '_default_1lane_kernel_stats.csv')
     cp('ks_default_1lane.json', R + '_default_1lane_bench_profiled.json')
     cp('ks_r50_1lane/p_kernel_stats.csv', R + '_r50_1lane_kernel_stats.csv')
-    for w in ('default', 'default_1lane', 'r100', 'r50', 'r50_1lane', 'r100_arc', 'r100_1m_bf16x3', 'frames'):
+    for w in ('default', 'default_1lane', 'r100', 'r50', 'r50_1lane', 'r100_arc', 'r100_1m_bf16x3', 'r100_1m_bf16x2', 'frames', 'default_fc'):
         cp('bench_%s.json' % w, '%s_%s_bench.json' % (R, w))
     for src, dst in (('layers_r100.txt', 'r100_b256_layers.txt'), ('layers_r50.txt', 'r50_b256_layers.txt'),
-                     ('layers_r100_bf16x3.txt', 'r100_b256_bf16x3_layers.txt'), ('layers_yolov3.txt', 'yolov3_b64_layers.txt'),
-                     ('latency.txt', 'latency.txt'), ('batch_sweep.txt', 'batch_sweep.txt'), ('zero_weights.txt', 'bf16x3_zero_weights.txt'),
-                     ('match_ab.txt', 'match_filter_ab.txt')):
+                     ('layers_r100_bf16x2.txt', 'r100_b256_bf16x2_layers.txt'), ('layers_yolov3.txt', 'yolov3_b64_layers.txt'),
+                     ('latency.txt', 'latency.txt'), ('batch_sweep.txt', 'batch_sweep.txt'), ('bf_tier_gates.txt', 'bf_tier_gates.txt'),
+                     ('match_ab.txt', 'match_filter_ab.txt'), ('match_pmc_table.txt', 'match_wave_states.txt')):
         cp(src, R + '_' + src.replace(src, dst))
     # forwards per profiled run, in units of the workload's batch: bench.py reports them (`forwards_in_process`:
     # steps + warmup, the per-layer profile, the warm-up and the stamped forward of the clock measurement, and the
     # batch-256 forwards of the default workload)
     def equiv_forwards(tag, batch):
         f = jl(os.path.join(OUT, tag + '.json'))['forwards_in_process']
-        return sum(int(b) * n for b, n in f.items()) / float(batch)
+        return sum(int(b) * n for b, n in f.items() if b.isdigit()) / float(batch)
     tool('pmc_traffic.py', [os.path.join(OUT, 'pf_default/p_counter_collection.csv'),
                             os.path.join(OUT, 'pw_default/p_counter_collection.csv'), '%g' % equiv_forwards('pf_default', 512)],
          R + '_r100_1m_b512_hbm_traffic.json')
@@ -71,8 +71,8 @@ def main():
                             os.path.join(OUT, 'pw_r50/p_counter_collection.csv'), '%g' % equiv_forwards('pf_r50', 256)],
          R + '_r50_b256_hbm_traffic.json')
     tool('pmc_mfma.py', [os.path.join(OUT, 'pm_default/p_counter_collection.csv')], R + '_r100_1m_mfma_util.json')
-    tool('pmc_mfma.py', [os.path.join(OUT, 'pm_bf16x3/p_counter_collection.csv')], R + '_r100_1m_bf16x3_mfma_util.json')
-    for src, dst in (('trace_r100_f32.txt', '_r100_b256_block_trace.txt'), ('trace_r100_bf16x3.txt', '_r100_b256_bf16x3_block_trace.txt'),
+    tool('pmc_mfma.py', [os.path.join(OUT, 'pm_bf16x2/p_counter_collection.csv')], R + '_r100_1m_bf16x2_mfma_util.json')
+    for src, dst in (('trace_r100_f32.txt', '_r100_b256_block_trace.txt'), ('trace_r100_bf16x2.txt', '_r100_b256_bf16x2_block_trace.txt'),
                      ('trace_r50_f32.txt', '_r50_b256_block_trace.txt'), ('place_r100_f32.txt', '_r100_b256_block_placement.txt')):
         if not os.path.exists(os.path.join(OUT, src)):
             continue
@@ -90,6 +90,12 @@ def main():
                  '%.2f ms in the same run; frac from the stats %.4f vs bench %.4f'
                  % (calls, ms, per_fw, one['roofline']['forward_ms_hip_events'], flops / (per_fw * 1e-3) / 1e12 / PEAK,
                     one['roofline']['frac']))
+    # the match filter kernel of the same profiled run: per-launch duration from the stats vs the HIP-event match phase
+    for r in csv.DictReader(open(os.path.join(OUT, 'ks_default_1lane/p_kernel_stats.csv'))):
+        if 'match_bd_kernel' in r['Name']:
+            lines.append('match_bd_kernel in that run: %s calls, %.1f us average (kernel-trace stats) vs match phase %.3f ms by HIP events '
+                         '(the phase also holds probe_eps / split2_frag / finish / exact / output)'
+                         % (r['Calls'], float(r['AverageNs']) / 1e3, one['phases_ms']['match']))
     d = jl(os.path.join(OUT, 'bench_default.json'))
     dp = jl(os.path.join(OUT, 'ks_default.json'))
     lines.append('default workload, default executor (two lanes): un-profiled %.0f faces/s, forward %.2f ms, frac %.4f (b256: '
@@ -97,6 +103,12 @@ def main():
                  % (d['value'], d['roofline']['forward_ms_hip_events'], d['roofline']['frac'],
                     d['roofline']['b256']['forward_ms_hip_events'], d['roofline']['b256']['frac'], d['phases_ms']['match'],
                     dp['value'], dp['roofline']['frac']))
+    m = d['roofline']['match']
+    lines.append('match roofline of that line: %.3f ms, %.1f TFLOP/s of the %.0f ceiling = %.3f (MFMA floor %.3f ms, HBM floor %.3f ms); '
+                 'combined (t_roof embed + t_roof match) / step = %.4f; throughput_mode: %s %.2f ms = %.3fx'
+                 % (m['ms'], m['tflops'], m['ceiling_tflops'], m['frac'], m['mfma_floor_ms'], m['hbm_floor_ms'],
+                    d['roofline']['combined']['frac'], d['throughput_mode']['tier'], d['throughput_mode']['forward_ms_hip_events'],
+                    d['throughput_mode']['speedup_vs_float32_forward']))
     # cross-check 2: ResNet-50V2 one lane
     r50 = jl(os.path.join(OUT, 'bench_r50_1lane.json'))
     ms, calls = conv_ms(os.path.join(OUT, 'ks_r50_1lane/p_kernel_stats.csv'))
@@ -104,7 +116,7 @@ def main():
     lines.append('r50 (configs[1]), ONE lane: %d conv launches per forward, %.3f ms of conv kernels per forward (stats) vs HIP-event '
                  'forward %.3f ms (un-profiled run), frac %.4f' % (round(calls / fw50), ms / fw50, r50['roofline']['forward_ms_hip_events'],
                                                                   r50['roofline']['frac']))
-    for w in ('r100', 'r50', 'r100_arc', 'r100_1m_bf16x3', 'frames'):
+    for w in ('r100', 'r50', 'r100_arc', 'r100_1m_bf16x3', 'r100_1m_bf16x2', 'frames', 'default_fc'):
         b = jl(os.path.join(OUT, 'bench_%s.json' % w))
         lines.append('%-16s %8.0f %s  step %.2f ms  phases %s  frac(f32 peak) %.4f'
                      % (w, b['value'], b['unit'], b['ms_per_step'], json.dumps(b['phases_ms']), b['roofline']['frac']))

@@ -1,11 +1,11 @@
 #!/bin/bash
-# Round-3 evidence run, on the GPU box (via gpurun): rocprofv3 kernel-trace stats of the EXACT driver command
+# Round-4 evidence run, on the GPU box (via gpurun): rocprofv3 kernel-trace stats of the EXACT driver command
 # (python3 bench.py --gpus 1 --steps 20 --warmup 5), separate PMC passes (never combined with tracing), the
 # un-profiled bench lines of every workload, per-layer tables and the small-batch latency table.
-# Outputs land in gpurun_out/r03/; tools/check_profiles.py copies the summaries into profiles/.
+# Outputs land in gpurun_out/r04/; tools/check_profiles.py copies the summaries into profiles/.
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r03
+O=gpurun_out/r04
 mkdir -p $O
 prof() { local tag=$1; shift; rocprofv3 "$@" --output-format csv -d $O/$tag -o p -- python3 bench.py --gpus 1 ${ARGS} > $O/$tag.json 2> $O/$tag.err; }
 # 1. the driver's command, default executor (two lanes: kernel durations of the two streams overlap)
@@ -29,19 +29,22 @@ python3 bench.py --workload r50 > $O/bench_r50.json 2>/dev/null &&
 DIF_STREAMS=1 python3 bench.py --workload r50 --no-cpu-baseline > $O/bench_r50_1lane.json 2>/dev/null &&
 python3 bench.py --workload r100_arc --no-cpu-baseline > $O/bench_r100_arc.json 2>/dev/null &&
 python3 bench.py --workload r100_1m_bf16x3 --no-cpu-baseline > $O/bench_r100_1m_bf16x3.json 2>/dev/null &&
+python3 bench.py --workload r100_1m_bf16x2 --no-cpu-baseline > $O/bench_r100_1m_bf16x2.json 2>/dev/null &&
+python3 bench.py --force-collectives --no-cpu-baseline --no-throughput-mode > $O/bench_default_fc.json 2>/dev/null &&
 python3 bench.py --workload frames --steps 3 --warmup 1 > $O/bench_frames.json 2>/dev/null &&
 # 5. per-layer tables, latency
 python3 tools/layer_profile.py iresnet100 256 > $O/layers_r100.txt 2>&1 &&
 python3 tools/layer_profile.py resnet 256 > $O/layers_r50.txt 2>&1 &&
-python3 tools/layer_profile.py iresnet100 256 bf16x3 > $O/layers_r100_bf16x3.txt 2>&1 &&
+python3 tools/layer_profile.py iresnet100 256 bf16x2 > $O/layers_r100_bf16x2.txt 2>&1 &&
 python3 tools/layer_profile.py yolov3 64 > $O/layers_yolov3.txt 2>&1 &&
 python3 tools/latency.py > $O/latency.txt 2>&1 &&
-DIF_STREAMS=1 ARGS="--workload r100_1m_bf16x3 --steps 3 --warmup 1 --no-cpu-baseline" prof pm_bf16x3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE &&
+DIF_STREAMS=1 ARGS="--workload r100_1m_bf16x2 --steps 3 --warmup 1 --no-cpu-baseline" prof pm_bf16x2 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE &&
 DIF_OPTIONS=dbg=256 python3 tools/bf3_trace.py 256 f32 2> $O/trace_r100_f32.txt > /dev/null &&
-DIF_OPTIONS=dbg=256 python3 tools/bf3_trace.py 256 bf16x3 2> $O/trace_r100_bf16x3.txt > /dev/null &&
+DIF_OPTIONS=dbg=256 python3 tools/bf3_trace.py 256 bf16x2 2> $O/trace_r100_bf16x2.txt > /dev/null &&
 DIF_OPTIONS=dbg=256 python3 tools/bf3_trace.py 256 f32 resnet 2> $O/trace_r50_f32.txt > /dev/null &&
 DIF_OPTIONS=dbg=768 python3 tools/bf3_trace.py 256 f32 2> $O/place_r100_f32.txt > /dev/null &&
 (for b in 64 128 256 512 1024; do python3 tools/time_embed.py iresnet100 $b 2>/dev/null | tail -1; done; for b in 64 128 256 512 1024 2048; do python3 tools/time_embed.py resnet $b 2>/dev/null | tail -1; done) > $O/batch_sweep.txt &&
-python3 tools/bf3_zero.py bf16x3 2>/dev/null | tail -2 > $O/zero_weights.txt && python3 tools/bf3_zero.py f32 2>/dev/null | tail -2 >> $O/zero_weights.txt &&
-python3 tools/match_ab.py 2>/dev/null | tail -4 > $O/match_ab.txt
+python3 tools/bf_tier_gates.py 256 512 2>/dev/null | grep -v amdgpu > $O/bf_tier_gates.txt &&
+python3 tools/match_ab.py 2>/dev/null | tail -4 > $O/match_ab.txt &&
+(bash tools/pmc_match.sh > /dev/null 2>&1; cp gpurun_out/match_pmc/table.txt $O/match_pmc_table.txt)
 echo "collect rc=$?"
