@@ -78,6 +78,105 @@ __global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restric
   }
 }
 
+// One destination pixel of cv2.resize(src[ch x cw], (SW, SH), interpolation=INTER_AREA) for uint8 images, operation by
+// operation as OpenCV's resize.cpp performs it (restated in oracle/imageops.py: area_resize, which this must equal bit for
+// bit; PARITY UNPINNED against cv2 itself, which is not installed here):
+//   both axes shrink or stay: 2 x 2 blocks (a + b + c + d + 2) >> 2; other integer ratios cvRound(float(sum) * (1.f / area));
+//     fractional ratios the DecimateAlpha tables -- per axis (source index, float32 weight) pairs from double arithmetic --
+//     with buf = sum_k S * alpha_k per source row and sum = sum_j beta_j * buf_j, every product and addition rounded to
+//     float32 in table order (no fused multiply-add), cvRound at the end;
+//   an axis enlarges: both axes take the linear path with area-mode coefficients in 11-bit fixed point.
+// `src` points at the crop's first pixel, `pitch` = pixels per source row.
+struct AreaTaps {                 // computeResizeAreaTab for one destination index: a head, a run of full cells, a tail
+  int s_head, s_run0, s_run1, s_tail;       // -1: absent
+  float a_head, a_run, a_tail;
+};
+__device__ __forceinline__ AreaTaps area_taps(int d, int ssize, double scale) {
+  AreaTaps t;
+  const double f1 = __dmul_rn((double)d, scale), f2 = __dadd_rn(f1, scale);    // (no fused multiply-add: cv2 rounds the product)
+  const double cell = fmin(scale, ssize - f1);
+  int s1 = (int)ceil(f1), s2 = (int)floor(f2);
+  s2 = s2 < ssize - 1 ? s2 : ssize - 1;
+  s1 = s1 < s2 ? s1 : s2;
+  t.s_head = (s1 - f1 > 1e-3) ? s1 - 1 : -1;
+  t.a_head = (float)((s1 - f1) / cell);
+  t.s_run0 = s1;
+  t.s_run1 = s2;
+  t.a_run = (float)(1.0 / cell);
+  t.s_tail = (f2 - s2 > 1e-3) ? s2 : -1;
+  t.a_tail = (float)(fmin(fmin(f2 - s2, 1.0), cell) / cell);
+  return t;
+}
+__device__ __forceinline__ void linear_taps(int d, int ssize, int dsize, int& s0, int& s1, int& a0, int& a1) {
+  const double inv = (double)dsize / ssize, scale = 1.0 / inv;
+  int sx = (int)floor(__dmul_rn((double)d, scale));
+  float fx = (float)__dsub_rn((double)(d + 1), __dmul_rn((double)(sx + 1), inv));
+  fx = fx <= 0.f ? 0.f : fx - floorf(fx);
+  if (sx < 0) { fx = 0.f; sx = 0; }
+  if (sx >= ssize - 1) { fx = 0.f; sx = ssize - 1; }
+  s0 = sx;
+  s1 = sx + 1 < ssize ? sx + 1 : ssize - 1;
+  a0 = (int)rintf(__fmul_rn(1.f - fx, 2048.f));
+  a1 = (int)rintf(__fmul_rn(fx, 2048.f));
+}
+__device__ __forceinline__ void area_pixel(const uint8_t* __restrict__ src, int pitch, int cw, int ch, int SW, int SH, int x, int y,
+                                           uint8_t* __restrict__ o) {
+  const double scale_x = 1.0 / ((double)SW / cw), scale_y = 1.0 / ((double)SH / ch);
+  if (scale_x >= 1.0 && scale_y >= 1.0) {
+    const int ix = (int)scale_x, iy = (int)scale_y;
+    if (fabs(scale_x - ix) < 2.220446049250313e-16 && fabs(scale_y - iy) < 2.220446049250313e-16) {
+      int sum[3] = {0, 0, 0};
+      for (int yy = 0; yy < iy; ++yy)
+        for (int xx = 0; xx < ix; ++xx) {
+          const uint8_t* p = src + ((int64_t)(y * iy + yy) * pitch + (x * ix + xx)) * 3;
+          sum[0] += p[0];
+          sum[1] += p[1];
+          sum[2] += p[2];
+        }
+      const float sc = 1.f / (float)(ix * iy);
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        o[c] = (ix == 2 && iy == 2) ? (uint8_t)((sum[c] + 2) >> 2) : (uint8_t)fminf(fmaxf(rintf(__fmul_rn((float)sum[c], sc)), 0.f), 255.f);
+      return;
+    }
+    const AreaTaps tx = area_taps(x, cw, scale_x), ty = area_taps(y, ch, scale_y);
+    float sum[3] = {0.f, 0.f, 0.f};
+    bool first = true;
+    auto row = [&](int sy, float beta) {
+      const uint8_t* r = src + (int64_t)sy * pitch * 3;
+      float buf[3] = {0.f, 0.f, 0.f};
+      auto tap = [&](int sx, float alpha) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) buf[c] = __fadd_rn(buf[c], __fmul_rn((float)r[sx * 3 + c], alpha));
+      };
+      if (tx.s_head >= 0) tap(tx.s_head, tx.a_head);
+      for (int sx = tx.s_run0; sx < tx.s_run1; ++sx) tap(sx, tx.a_run);
+      if (tx.s_tail >= 0) tap(tx.s_tail, tx.a_tail);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) sum[c] = first ? __fmul_rn(beta, buf[c]) : __fadd_rn(sum[c], __fmul_rn(beta, buf[c]));
+      first = false;
+    };
+    if (ty.s_head >= 0) row(ty.s_head, ty.a_head);
+    for (int sy = ty.s_run0; sy < ty.s_run1; ++sy) row(sy, ty.a_run);
+    if (ty.s_tail >= 0) row(ty.s_tail, ty.a_tail);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = (uint8_t)fminf(fmaxf(rintf(sum[c]), 0.f), 255.f);
+    return;
+  }
+  int x0, x1, a0, a1, y0, y1, b0, b1;
+  linear_taps(x, cw, SW, x0, x1, a0, a1);
+  linear_taps(y, ch, SH, y0, y1, b0, b1);
+  const uint8_t* r0 = src + (int64_t)y0 * pitch * 3;
+  const uint8_t* r1 = src + (int64_t)y1 * pitch * 3;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int h0 = r0[x0 * 3 + c] * a0 + r0[x1 * 3 + c] * a1, h1 = r1[x0 * 3 + c] * a0 + r1[x1 * 3 + c] * a1;
+    int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    o[c] = (uint8_t)v;
+  }
+}
+
 // boxes: [N][4] = left, top, right, bottom in frame pixels (as detector/run.py:114 returns them)
 __global__ __launch_bounds__(256) void crop_resize_kernel(const uint8_t* __restrict__ frames, int N, int H, int W,
                                                           const float* __restrict__ boxes, float margin,
@@ -102,30 +201,7 @@ __global__ __launch_bounds__(256) void crop_resize_kernel(const uint8_t* __restr
       continue;
     }
     const uint8_t* img = frames + n * (int64_t)H * W * 3;
-    const float sx = (float)cw / SW, sy = (float)ch / SH;
-    float acc[3] = {0.f, 0.f, 0.f};
-    {
-      // cv2 INTER_AREA: the output pixel's footprint in the crop, source pixels weighted by the
-      // covered fraction (when enlarging this touches at most 2x2 pixels -- cv2's area-mode
-      // linear coefficients are the same coverage fractions)
-      const float x0 = x * sx, x1 = (x + 1) * sx, y0 = y * sy, y1 = (y + 1) * sy;
-      float wsum = 0.f;
-      for (int yy = (int)y0; yy < ch && yy < (int)ceilf(y1); ++yy) {
-        const float wy = fminf(y1, yy + 1.f) - fmaxf(y0, (float)yy);
-        const uint8_t* row = img + ((int64_t)(t + yy) * W + l) * 3;
-        for (int xx = (int)x0; xx < cw && xx < (int)ceilf(x1); ++xx) {
-          const float w = wy * (fminf(x1, xx + 1.f) - fmaxf(x0, (float)xx));
-          acc[0] = fmaf(w, (float)row[xx * 3], acc[0]);
-          acc[1] = fmaf(w, (float)row[xx * 3 + 1], acc[1]);
-          acc[2] = fmaf(w, (float)row[xx * 3 + 2], acc[2]);
-          wsum += w;
-        }
-      }
-      const float inv = wsum > 0.f ? 1.f / wsum : 0.f;
-      acc[0] *= inv; acc[1] *= inv; acc[2] *= inv;
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) o[c] = (uint8_t)fminf(fmaxf(rintf(acc[c]), 0.f), 255.f);
+    area_pixel(img + ((int64_t)t * W + l) * 3, W, cw, ch, SW, SH, x, y, o);
   }
 }
 

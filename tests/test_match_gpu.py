@@ -287,6 +287,17 @@ def test_match_near_ties_vs_golden(cuda, golden_dir, metric):
     for lo, hi in ((0, 1), (1, 34), (34, 48)):
         i2, _ = gal.match(probes[lo:hi], metric)
         assert np.array_equal(i2, g['idx%d' % metric][lo:hi])
+    # the same probes three times over and then some (48 -> 160 > 64 probes, ragged against the 128-probe tile): the
+    # B-direct filter kernel (match_bd_kernel, round 4) serves, with its wave-local candidate lists; 'bd' = 0 keeps the batch
+    # on match_tile_kernel.  Every copy of a probe must get the fixture's answer, on either kernel.
+    rep = np.concatenate([probes, probes, probes, probes[:16]])
+    want_rep = np.concatenate([g['idx%d' % metric]] * 3 + [g['idx%d' % metric][:16]])
+    for bd in (1, 0):
+        gal.set_option('bd', bd)
+        i5, d5 = gal.match(rep, metric)
+        assert np.array_equal(i5, want_rep), (bd, np.nonzero(i5 != want_rep)[0])
+        assert np.array_equal(d5[:48], dist, equal_nan=True)
+    gal.set_option('bd', 1)
     # the filter stage on the f32 MFMA instead of the two-term split-bf16 default: the same answers, bit for bit (the
     # filter only proposes candidates; the reference arithmetic decides)
     gal.set_option('filter', 0)
@@ -352,6 +363,11 @@ def test_match_degenerate_vs_golden(cuda, golden_dir, name):
             assert np.array_equal(dist[~nan].view(np.uint32), want_d[~nan].view(np.uint32))
         elif (~nan).any():
             assert np.abs(dist[~nan].view(np.int32).astype(np.int64) - want_d[~nan].view(np.int32)).max() <= 4
+        # more than 64 probes (the fixture's, repeated): match_bd_kernel and its wave-local epilogue on the same inputs
+        reps = (80 + B - 1) // B + 1
+        i6, d6 = gal.match(np.concatenate([probes] * reps), metric)
+        assert np.array_equal(i6, np.concatenate([want_i] * reps)), (metric, 'bd')
+        assert np.array_equal(np.isnan(d6), np.concatenate([nan] * reps))
         # ragged groups of probes (other tile shapes), on either filter (split-bf16 default, f32)
         for flt in (0, 1):
             gal.set_option('filter', flt)
@@ -487,3 +503,30 @@ def test_filter_option_in_any_order(cuda):
     with pytest.raises(ValueError):
         h.stat('nonsense')
     h.close()
+
+
+@pytest.mark.parametrize('G,B', [(300_003, 200), (70_000, 65), (1_000, 513)])
+def test_match_bd_kernel_equals_tile_kernel(cuda, G, B):
+    """The split-bf16 filter runs on match_bd_kernel from 65 probes up (256 x 128 tiles, probes in fragment order from L2, gallery
+    by LDS-DMA, candidate lists per wave row) and on match_tile_kernel below / with option 'bd' = 0: same candidates in the
+    end, so the same index, distance and key, bit for bit, both metrics -- gallery sizes that leave a ragged last tile of
+    256 rows, probe counts that leave a ragged 128-probe block and a ragged 32-probe fragment, a gallery smaller than one
+    tile per block, near-duplicate rows, and against the oracle on a sample."""
+    from deep_insight_face import oneshot
+    gen = torch.Generator(device='cuda').manual_seed(G + B)
+    gal_t = torch.nn.functional.normalize(torch.randn((G, 512), device='cuda', generator=gen), dim=1)
+    gal_t[G // 2:G // 2 + 40] = gal_t[7:47] * (1 + 1e-7)                      # near-duplicates far apart
+    pick = torch.randperm(G, device='cuda', generator=gen)[:B]
+    probes = torch.nn.functional.normalize(gal_t[pick] + 0.05 * torch.randn((B, 512), device='cuda', generator=gen), dim=1)
+    probes[B // 3] = -gal_t[5]                                                  # an anti-parallel pair
+    g = oneshot.Gallery(gal_t)
+    for metric in (0, 1):
+        g.set_option('bd', 1)
+        i1, d1, k1 = g.match(probes, metric, return_key=True)
+        g.set_option('bd', 0)
+        i0, d0, k0 = g.match(probes, metric, return_key=True)
+        assert torch.equal(i1, i0) and torch.equal(d1.view(torch.int32), d0.view(torch.int32)) and torch.equal(k1.view(torch.int32), k0.view(torch.int32))
+        rows = [0, 1, B // 3, B - 1]
+        oi, _, _ = od.match(probes[rows].cpu().numpy(), gal_t.cpu().numpy(), metric)
+        assert np.array_equal(i1[rows].cpu().numpy(), oi)
+    g.close()
