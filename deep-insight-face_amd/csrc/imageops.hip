@@ -1,3 +1,6 @@
+// hipcc-flags: -ffp-contract=fast-honor-pragmas
+// (build.py compiles with -ffp-contract=fast, which DISREGARDS `#pragma clang fp contract(off)`: area_pixel below restates cv2's
+// float32 arithmetic operation by operation and needs the pragma honoured; the other kernels of this file keep contraction)
 // Image resampling around the detector (BASELINE configs[4]: raw frames -> detect -> crop -> embed,
 // all on the device):
 //   letterbox_kernel   detector/yolov3.py:108-119 (letterbox_image): aspect-preserving resize with
@@ -92,8 +95,10 @@ struct AreaTaps {                 // computeResizeAreaTab for one destination in
   float a_head, a_run, a_tail;
 };
 __device__ __forceinline__ AreaTaps area_taps(int d, int ssize, double scale) {
+#pragma clang fp contract(off)      // (HIP's __fmul_rn / __dmul_rn are plain products: without this the compiler fuses them)
   AreaTaps t;
-  const double f1 = __dmul_rn((double)d, scale), f2 = __dadd_rn(f1, scale);    // (no fused multiply-add: cv2 rounds the product)
+  const double f1 = (double)d * scale;                      // (no fused multiply-add: cv2 rounds the product)
+  const double f2 = f1 + scale;
   const double cell = fmin(scale, ssize - f1);
   int s1 = (int)ceil(f1), s2 = (int)floor(f2);
   s2 = s2 < ssize - 1 ? s2 : ssize - 1;
@@ -108,19 +113,24 @@ __device__ __forceinline__ AreaTaps area_taps(int d, int ssize, double scale) {
   return t;
 }
 __device__ __forceinline__ void linear_taps(int d, int ssize, int dsize, int& s0, int& s1, int& a0, int& a1) {
+#pragma clang fp contract(off)
   const double inv = (double)dsize / ssize, scale = 1.0 / inv;
-  int sx = (int)floor(__dmul_rn((double)d, scale));
-  float fx = (float)__dsub_rn((double)(d + 1), __dmul_rn((double)(sx + 1), inv));
+  const double dsc = (double)d * scale;
+  int sx = (int)floor(dsc);
+  const double back = (double)(sx + 1) * inv;
+  float fx = (float)((double)(d + 1) - back);
   fx = fx <= 0.f ? 0.f : fx - floorf(fx);
   if (sx < 0) { fx = 0.f; sx = 0; }
   if (sx >= ssize - 1) { fx = 0.f; sx = ssize - 1; }
   s0 = sx;
   s1 = sx + 1 < ssize ? sx + 1 : ssize - 1;
-  a0 = (int)rintf(__fmul_rn(1.f - fx, 2048.f));
-  a1 = (int)rintf(__fmul_rn(fx, 2048.f));
+  const float c0 = 1.f - fx;
+  a0 = (int)rintf(c0 * 2048.f);
+  a1 = (int)rintf(fx * 2048.f);
 }
 __device__ __forceinline__ void area_pixel(const uint8_t* __restrict__ src, int pitch, int cw, int ch, int SW, int SH, int x, int y,
                                            uint8_t* __restrict__ o) {
+#pragma clang fp contract(off)      // every product and sum below is rounded by itself, as in OpenCV's scalar code
   const double scale_x = 1.0 / ((double)SW / cw), scale_y = 1.0 / ((double)SH / ch);
   if (scale_x >= 1.0 && scale_y >= 1.0) {
     const int ix = (int)scale_x, iy = (int)scale_y;
@@ -136,24 +146,32 @@ __device__ __forceinline__ void area_pixel(const uint8_t* __restrict__ src, int 
       const float sc = 1.f / (float)(ix * iy);
 #pragma unroll
       for (int c = 0; c < 3; ++c)
-        o[c] = (ix == 2 && iy == 2) ? (uint8_t)((sum[c] + 2) >> 2) : (uint8_t)fminf(fmaxf(rintf(__fmul_rn((float)sum[c], sc)), 0.f), 255.f);
+        o[c] = (ix == 2 && iy == 2) ? (uint8_t)((sum[c] + 2) >> 2) : (uint8_t)fminf(fmaxf(rintf((float)sum[c] * sc), 0.f), 255.f);
       return;
     }
     const AreaTaps tx = area_taps(x, cw, scale_x), ty = area_taps(y, ch, scale_y);
     float sum[3] = {0.f, 0.f, 0.f};
     bool first = true;
     auto row = [&](int sy, float beta) {
+#pragma clang fp contract(off)      // (the pragma of the enclosing function does not reach into a lambda's body)
       const uint8_t* r = src + (int64_t)sy * pitch * 3;
       float buf[3] = {0.f, 0.f, 0.f};
       auto tap = [&](int sx, float alpha) {
+#pragma clang fp contract(off)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) buf[c] = __fadd_rn(buf[c], __fmul_rn((float)r[sx * 3 + c], alpha));
+        for (int c = 0; c < 3; ++c) {
+          const float prod = (float)r[sx * 3 + c] * alpha;      // plain operators under the pragma (HIP's __fmul_rn / __fadd_rn
+          buf[c] = buf[c] + prod;                                // are header functions compiled with contraction ON)
+        }
       };
       if (tx.s_head >= 0) tap(tx.s_head, tx.a_head);
       for (int sx = tx.s_run0; sx < tx.s_run1; ++sx) tap(sx, tx.a_run);
       if (tx.s_tail >= 0) tap(tx.s_tail, tx.a_tail);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) sum[c] = first ? __fmul_rn(beta, buf[c]) : __fadd_rn(sum[c], __fmul_rn(beta, buf[c]));
+      for (int c = 0; c < 3; ++c) {
+        const float prod = beta * buf[c];
+        sum[c] = first ? prod : sum[c] + prod;
+      }
       first = false;
     };
     if (ty.s_head >= 0) row(ty.s_head, ty.a_head);
