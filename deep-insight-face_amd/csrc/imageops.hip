@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restric
 }
 
 // One destination pixel of cv2.resize(src[ch x cw], (SW, SH), interpolation=INTER_AREA) for uint8 images, operation by
-// operation as OpenCV's resize.cpp performs it (restated in oracle/imageops.py: area_resize, which this must equal bit for
+// operation as OpenCV's resize.cpp performs it (the test suite's checker restates the same paths and must be equalled bit for
 // bit; PARITY UNPINNED against cv2 itself, which is not installed here):
 //   both axes shrink or stay: 2 x 2 blocks (a + b + c + d + 2) >> 2; other integer ratios cvRound(float(sum) * (1.f / area));
 //     fractional ratios the DecimateAlpha tables -- per axis (source index, float32 weight) pairs from double arithmetic --
