@@ -2161,6 +2161,7 @@ static bool pw_applies(const ConvArgs& a) {
   // 64 input channels = two K-steps per tile: those layers stream (460 MB in 115 us on ResNet-50V2's 28 x 28 stage) and the
   // persistent pipelined kernel, which retires a tile's stores under the next tile's loads, moves them 5 % faster
   if (a.Cin < 128 && !(a.dbg & 8)) return false;
+  if ((a.dbg & 64) && !(a.Cout >= 1024 || a.Cin >= 2048)) return false;     // ablation: only the layers it won on one lane
   return true;
 }
 
