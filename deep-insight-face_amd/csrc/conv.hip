@@ -1919,6 +1919,205 @@ static bool pipe_applies(const ConvArgs& a, int64_t tiles, int KS, int64_t slots
 }
 
 // ------------------------------------------------------------------------------------------
+// conv_t2_kernel (round 4): 3x3 / stride 1 layers on maps whose sides are multiples of 8, with a
+// 128-pixel x 64-channel tile per block -- TWO consecutive 8x8 tiles of the 8x8-tile order, one per wave row, each with its
+// own 10 x 10 halo patch (200 entries, 25.6 KB) -- instead of one: a wave owns 64 pixels x 32 channels (two row fragments),
+// so a B fragment fetched from L2 feeds 32 MFMAs instead of 16 and a tile's set-up and epilogue are paid once per 128
+// pixels.  Meant for IResNet's 64-channel 112 x 112 / 56 x 56 layers (18 K-steps per tile: 18 us of mainloop beside
+// 10-12 us of set-up and epilogue on the 64 x 64 kernel).  Same B-direct mainloop as gemm_mainloop_patch_bd, same
+// accumulation order per output element (K-step, half, t): bit-identical.  One whole tile per block (no stream-K).
+using TileT2 = Tile<2, 1, 2, 2>;
+
+struct PatchA2D2 {
+  static constexpr int EMAX = 200, SIDE = 10, NPC = (EMAX * 8 + 255) / 256;
+  __amdgpu_buffer_rsrc_t rsrc;
+  int base[2];              // entry of this lane's output pixels (row fragment mi of the wave row's sub-tile), tap (0, 0)
+  int hw0[2], ioff[2];      // per sub-tile: (h0 - 1) << 16 | (w0 - 1) & 0xffff; its image's offset in pixels from the first image
+  int H, W, Cin4;
+  __device__ __forceinline__ PatchA2D2(const ConvArgs& a, int m0) {
+    const int lane = threadIdx.x & 63;
+    H = a.H;
+    W = a.W;
+    Cin4 = a.Cin * 4;
+    int n0, h0, w0, n1, h1, w1;
+    tile2d_pix0(a, m0, n0, h0, w0);
+    const bool second = m0 + 64 < a.M;
+    tile2d_pix0(a, second ? m0 + 64 : m0, n1, h1, w1);
+    const int64_t img_elems = (int64_t)a.H * a.W * a.Cin;
+    rsrc = make_rsrc(a.x + n0 * img_elems, (uint32_t)((n1 - n0 + 1) * img_elems * 4));
+    hw0[0] = ((h0 - 1) << 16) | ((w0 - 1) & 0xffff);
+    hw0[1] = second ? (((h1 - 1) << 16) | ((w1 - 1) & 0xffff)) : (int)0xc000c000;     // far outside: every entry reads zero
+    ioff[0] = 0;
+    ioff[1] = (n1 - n0) * a.H * a.W;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int r = mi * 32 + (lane & 31);
+      base[mi] = TileT2::wave_row() * 100 + (r >> 3) * SIDE + (r & 7);
+    }
+  }
+  __device__ __forceinline__ void load(int cblk, f32x4 (&pr)[NPC]) const {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));                          // offsets recomputed per slice, not kept (two slices per tile here)
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      const int slot = tid + 256 * j;
+      const int e = slot >> 3, q = slot & 7;
+      const int sub = e >= 100 ? 1 : 0, el = e - 100 * sub;
+      const int py = (el * 205) >> 11, px = el - py * SIDE;          // el / 10 for el < 1024
+      const int hi = (hw0[sub] >> 16) + py, wi = (int)(short)(hw0[sub] & 0xffff) + px;
+      const bool ok = e < EMAX && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+      const int chunk = q ^ patch_swz(e);
+      pr[j] = buf_load4(rsrc, ok ? (uint32_t)((ioff[sub] + hi * W + wi) * Cin4 + chunk * 16 + cblk * 128) : OOB);
+    }
+  }
+  __device__ __forceinline__ void store(float* patch, const f32x4 (&pr)[NPC]) const {
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      const int slot = threadIdx.x + 256 * j;
+      if (slot < EMAX * 8) *reinterpret_cast<f32x4*>(patch + slot * 4) = pr[j];
+    }
+  }
+};
+
+__device__ __forceinline__ void t2_mainloop(const PatchA2D2& pa, const ConvArgs& a, int n0, float* patch, f32x16 (&acc)[2][1]) {
+  const int lane = threadIdx.x & 63, h = lane >> 5;
+  const int KS = a.Kpad / BK;
+  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.w_frag, a.w_frag_bytes);
+  const uint32_t lane_off = (uint32_t)((n0 >> 5) + TileT2::wave_col()) * (uint32_t)KS * 4096u + (uint32_t)lane * 16u;
+  auto bload = [&](int ks, int s, f32x4 (&b)[2]) {
+    const uint32_t so = (uint32_t)ks * 4096u + (uint32_t)s * 2048u;
+    b[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane_off, so, 0));
+    b[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane_off + 1024u, so, 0));
+  };
+  f32x4 pr[PatchA2D2::NPC], bA[2], bB[2];
+  int cb = 0, tap = 0, kw = 0, eoff = 0;
+  pa.load(0, pr);
+  bload(0, 0, bA);
+  pa.store(patch, pr);
+  lds_barrier();
+  bool pf_issued = false;
+  const char* patch_b = reinterpret_cast<const char*>(patch);
+  const uint32_t l0x = (uint32_t)(2 * h);
+  auto frag_addr = [&](int m) -> uint32_t {
+    const uint32_t e = (uint32_t)(pa.base[m] + eoff);
+    return (e << 7) | ((l0x ^ ((e >> 1) & 7u)) << 4);
+  };
+  auto read_frag = [&](uint32_t a0, int s, f32x4 (&f)[2]) {
+    f[0] = *reinterpret_cast<const f32x4*>(patch_b + (a0 ^ (uint32_t)(64 * s)));
+    f[1] = *reinterpret_cast<const f32x4*>(patch_b + (a0 ^ (uint32_t)(64 * s + 16)));
+  };
+  auto mfma16 = [&](const f32x4 (&f)[2][2], const f32x4 (&b)[2]) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[m][q][t], b[q][t], acc[m][0], 0, 0, 0);
+  };
+  f32x4 fa[2][2], fn[2][2];
+  uint32_t a0[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    a0[m] = frag_addr(m);
+    read_frag(a0[m], 0, fa[m]);
+  }
+  for (int ks = 0; ks < KS; ++ks) {
+    const bool more = ks + 1 < KS;
+    bload(ks, 1, bB);
+    if (!pf_issued && tap >= PATCH_PF_TAP && (cb + 1) * 9 < KS) {
+      pa.load(cb + 1, pr);
+      pf_issued = true;
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) read_frag(a0[m], 1, fn[m]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma16(fa, bA);
+    bload(more ? ks + 1 : ks, 0, bA);                      // (past the last step: a harmless refetch, no branch around loads)
+    if (++kw == 3) {
+      kw = 0;
+      eoff += PatchA2D2::SIDE - 2;
+    } else {
+      ++eoff;
+    }
+    const bool swap = ++tap == 9;
+    if (!swap && more) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        a0[m] = frag_addr(m);
+        read_frag(a0[m], 0, fa[m]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma16(fn, bB);
+    if (swap && more) {
+      tap = 0;
+      eoff = 0;
+      ++cb;
+      lds_barrier();
+      pa.store(patch, pr);
+      pf_issued = false;
+      lds_barrier();
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        a0[m] = frag_addr(m);
+        read_frag(a0[m], 0, fa[m]);
+      }
+    }
+  }
+  lds_barrier();
+}
+
+template <bool YSUB>      // YSUB: the first output keeps its even pixels only (ConvArgs::y_sub)
+__global__ __launch_bounds__(256, 3) void conv_t2_kernel(const ConvArgs a, int tiles_n, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) float t2_smem[];
+  const int tile = xcd_remap((int)blockIdx.x, ntiles);
+  const int mt = tile / tiles_n, nt = tile - mt * tiles_n;
+  const int m0 = mt * TileT2::BM, n0 = nt * TileT2::BN;
+  f32x16 acc[2][1];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][0][r] = 0.f;
+  {
+    const PatchA2D2 pa(a, m0);
+    t2_mainloop(pa, a, n0, t2_smem, acc);
+  }
+  EpiRes<TileT2> er;
+  conv_epilogue_fast<TileT2, true, YSUB>(a, acc, m0, n0, t2_smem, er, false);
+}
+
+// conv_t2_kernel's layers: the 8x8-tile patch layers with a SHORT K loop (the long ones have conv_bdp_kernel), weights in
+// fragment order, whole 64-channel column tiles, the lean epilogue's plain geometry (no sub-sampled first output)
+static bool t2_applies(const ConvArgs& a) {
+  if (a.off & CONV_OFF_T2) return false;                    // Net option "t2" = 0
+  if (!patch2d_applies(a) || !a.w_frag || (a.off & CONV_OFF_BD) || a.Cout % 64 != 0 || a.Kpad / BK >= 32) return false;
+  if ((a.dbg & 1024) || !(a.y_H == a.Ho && a.y_W == a.Wo && a.y_oy == 0 && a.y_ox == 0 && a.y_ld == a.Cout && a.y_coff == 0)) return false;
+  if (a.res && (a.res_stride != 1 || a.res_H != a.Ho || a.res_W != a.Wo)) return false;
+  if ((int64_t)a.M * a.Cout * 4 >= 0xFFFFFFF0LL || (int64_t)2 * a.H * a.W * a.Cin * 4 >= 0x7fffffffLL) return false;
+  return a.M % 64 == 0;
+}
+
+static int launch_conv_t2(const ConvArgs& a, hipStream_t st) {
+  constexpr int lds = TileT2::BM * (TileT2::BN + 4) * 4 > PatchA2D2::EMAX * 128 ? TileT2::BM * (TileT2::BN + 4) * 4 : PatchA2D2::EMAX * 128;
+  if (allow_dynamic_lds(reinterpret_cast<const void*>(conv_t2_kernel<false>), lds)) return -1;
+  if (allow_dynamic_lds(reinterpret_cast<const void*>(conv_t2_kernel<true>), lds)) return -1;
+  const int tiles_m = (a.M + TileT2::BM - 1) / TileT2::BM, tiles_n = a.Cout / TileT2::BN;
+  const int64_t ntiles = (int64_t)tiles_m * tiles_n;
+  if (ntiles >= 0x7fffffffLL) return set_error("conv: too many tiles");
+  ConvArgs b = a;
+  b.fd_t2_w = make_fastdiv(a.W / 8);
+  b.fd_t2_img = make_fastdiv((a.H / 8) * (a.W / 8));
+  b.fd_howo = make_fastdiv(a.Ho * a.Wo);
+  b.fd_wo = make_fastdiv(a.Wo);
+  b.epi_fast = 1;
+  if (a.y_sub) hipLaunchKernelGGL(conv_t2_kernel<true>, dim3((unsigned)ntiles), dim3(256), lds, st, b, tiles_n, (int)ntiles);
+  else hipLaunchKernelGGL(conv_t2_kernel<false>, dim3((unsigned)ntiles), dim3(256), lds, st, b, tiles_n, (int)ntiles);
+  DIF_HIP(hipGetLastError());
+  g_last_kernel = "conv_t2_kernel<128x64,2x(patch8x8)+Bdirect>";
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // conv_pw_kernel: the pointwise (1 x 1 / stride 1) convolution as a BARRIER-FREE GEMM (round 4).
 //
 // ResNet-50V2 is 36 such layers out of 53 convolutions.  On conv_igemm / conv_pipe they stage both operands global ->
@@ -2230,6 +2429,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
     // (the 8x8-tile patch form ahead of the pipelined kernel, which took the short-K 3x3 layers -- 64 input channels -- before)
     const bool bd = !(a.off & CONV_OFF_BD) && a.w_frag != nullptr;
     if (patch2d_applies(a)) {
+      if (t2_applies(a)) return launch_conv_t2(a, st);
       if (bd && conv_bdp_ok(a)) return launch_conv_bdp<T, 6>(a, st);
       return bd ? launch_conv_pre<T, false, 16>(a, st) : launch_conv_pre<T, false, 6>(a, st);
     }

@@ -366,6 +366,32 @@ def test_pointwise_kernel_equals_general_kernels(cuda):
         m.close()
 
 
+def test_two_subtile_kernel_equals_plain_kernel(cuda):
+    """The short-K 3x3 layers on maps whose sides are multiples of 8 (IResNet's 64-channel 112 x 112 and 56 x 56 layers, VGG16's
+    first stages, the detector's) run on conv_t2_kernel (option 't2' = 0 keeps them on the 64 x 64 kernel): a 128-pixel x 64-channel tile of two 8x8 sub-tiles per block, two
+    row fragments per wave, one whole tile per block.  Same products in the same order per output element as the 64 x 64
+    kernel: the embeddings agree bit for bit up to the sign of an activation's zero.  Odd batches leave an odd number of
+    8x8 tiles (a block whose second sub-tile does not exist); IResNet's last 64-channel layer writes its first output at
+    even pixels only (y_sub)."""
+    import torch
+    from deep_insight_face.networks.triplet import DifEmbedder
+    rng = np.random.default_rng(47)
+    for arch, n in (('iresnet50', 9), ('iresnet50', 64), ('iresnet100', 3), ('vgg16', 5)):
+        x = torch.from_numpy(rng.integers(0, 256, (n, 112, 112, 3), dtype=np.uint8)).cuda()
+        m = DifEmbedder(arch, 'v2', 512, (112, 112, 3), max_batch=n).init_synthetic(14)
+        m.set_input_transform(scale=1 / 255.)
+        a = m.embed(x)
+        a2 = m.embed(x)
+        kernels = {k for _, k, _ in m.op_table()}
+        m.set_option('t2', 0)
+        b = m.embed(x)
+        assert not any(k.startswith('conv_t2_kernel') for _, k, _ in m.op_table())
+        assert torch.equal(a, a2)
+        assert any(k.startswith('conv_t2_kernel') for k in kernels), kernels
+        assert float((a - b).abs().max()) <= 2e-6, (arch, n, float((a - b).abs().max()))
+        m.close()
+
+
 def test_stem_kernels_equal_general_kernel(cuda):
     """3-channel first layers run on their own kernels: IResNet's 3x3 and ResNet50V2's 7x7 / stride 2 (64 filters) on
     the MFMA with the input patch in LDS and the true K (stem.hip), YOLOv3-face's 3x3 (32 filters) as a direct
