@@ -2563,6 +2563,9 @@ int conv_run(const ConvArgs& a, hipStream_t st) {
   // mainloop takes either -- measured the same as this one within 2 %)
   // (three or two bf16 terms per operand: ConvArgs::bf_terms, picked inside the kernel)
   const int form = bf3p_applies(a) * 2 + (a.Cout <= 64 ? 1 : 0);
+  // two-term tier: waves of 128 x 32 (four row fragments share a B fragment: half the B loads per MFMA, which with half the
+  // MFMAs per product is what the loop waits for; 47.6 -> 46.9 ms at batch 512, r04_ablation.txt item 7; three terms: +-0.4 %)
+  if (form == 2 && (a.bf_terms == 2 || (a.dbg & 128))) return launch_conv_pre<Tile<4, 1, 1, 4>, false, 13, 1>(a, st);
   switch (form) {
     case 2: return launch_conv_pre<Tile<2, 2, 2, 2>, false, 13, 1>(a, st);     // linear patch, 128 columns
     case 3: return launch_conv_pre<Tile<2, 1, 2, 2>, false, 13, 1>(a, st);     // linear patch, 64 columns
