@@ -2086,6 +2086,150 @@ __global__ __launch_bounds__(256, 3) void conv_t2_kernel(const ConvArgs a, int t
   conv_epilogue_fast<TileT2, true, YSUB>(a, acc, m0, n0, t2_smem, er, false);
 }
 
+// ------------------------------------------------------------------------------------------
+// conv_tn_kernel (round 4): the linear-patch 3x3 / stride 1 layers with a 64-pixel x 128-CHANNEL tile per block -- a wave
+// owns 32 pixels x 64 channels (two column fragments) -- one whole tile per block.  The same idea as conv_t2_kernel turned
+// by ninety degrees: an A fragment read from the LDS patch feeds 32 MFMAs instead of 16, and the patch (its fill, its swaps,
+// the tile's set-up) is paid once per 128 channels instead of once per 64 -- on IResNet's 28 x 28 stage (128 channels)
+// conv_bdp_kernel loads every patch twice, once per column tile.  B-direct mainloop, bit-identical accumulation order.
+using TileTN = Tile<1, 2, 2, 2>;
+
+template <int EMAX>
+__device__ __forceinline__ void tn_mainloop(const PatchA<TileTN, EMAX>& pa, const ConvArgs& a, int n0, float* patch,
+                                            f32x16 (&acc)[1][2]) {
+  using PA = PatchA<TileTN, EMAX>;
+  const int lane = threadIdx.x & 63, h = lane >> 5;
+  const int KS = a.Kpad / BK;
+  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.w_frag, a.w_frag_bytes);
+  uint32_t lane_off[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+    lane_off[n] = (uint32_t)((n0 >> 5) + TileTN::wave_col() * 2 + n) * (uint32_t)KS * 4096u + (uint32_t)lane * 16u;
+  auto bload = [&](int ks, int s, f32x4 (&b)[2][2]) {
+    const uint32_t so = (uint32_t)ks * 4096u + (uint32_t)s * 2048u;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      b[n][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane_off[n], so, 0));
+      b[n][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane_off[n] + 1024u, so, 0));
+    }
+  };
+  f32x4 pr[PA::NPC], bA[2][2], bB[2][2];
+  int cb = 0, tap = 0, kw = 0, eoff = 0;
+  pa.load(0, pr);
+  bload(0, 0, bA);
+  pa.store(patch, pr);
+  lds_barrier();
+  bool pf_issued = false;
+  const char* patch_b = reinterpret_cast<const char*>(patch);
+  const uint32_t l0x = (uint32_t)(2 * h);
+  auto frag_addr = [&]() -> uint32_t {
+    const uint32_t e = (uint32_t)(pa.base[0] + eoff);
+    return (e << 7) | ((l0x ^ ((e >> 1) & 7u)) << 4);
+  };
+  auto read_frag = [&](uint32_t a0, int s, f32x4 (&f)[2]) {
+    f[0] = *reinterpret_cast<const f32x4*>(patch_b + (a0 ^ (uint32_t)(64 * s)));
+    f[1] = *reinterpret_cast<const f32x4*>(patch_b + (a0 ^ (uint32_t)(64 * s + 16)));
+  };
+  auto mfma16 = [&](const f32x4 (&f)[2], const f32x4 (&b)[2][2]) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[q][t], b[n][q][t], acc[0][n], 0, 0, 0);
+  };
+  f32x4 fa[2], fn[2];
+  uint32_t a0 = frag_addr();
+  read_frag(a0, 0, fa);
+  for (int ks = 0; ks < KS; ++ks) {
+    const bool more = ks + 1 < KS;
+    bload(ks, 1, bB);
+    if (!pf_issued && tap >= PATCH_PF_TAP && (cb + 1) * 9 < KS) {
+      pa.load(cb + 1, pr);
+      pf_issued = true;
+    }
+    read_frag(a0, 1, fn);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma16(fa, bA);
+    bload(more ? ks + 1 : ks, 0, bA);
+    if (++kw == 3) {
+      kw = 0;
+      eoff += pa.WP - 2;
+    } else {
+      ++eoff;
+    }
+    const bool swap = ++tap == 9;
+    if (!swap && more) {
+      a0 = frag_addr();
+      read_frag(a0, 0, fa);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma16(fn, bB);
+    if (swap && more) {
+      tap = 0;
+      eoff = 0;
+      ++cb;
+      lds_barrier();
+      pa.store(patch, pr);
+      pf_issued = false;
+      lds_barrier();
+      a0 = frag_addr();
+      read_frag(a0, 0, fa);
+    }
+  }
+  lds_barrier();
+}
+
+template <int EMAX, bool YSUB>
+__global__ __launch_bounds__(256, 4) void conv_tn_kernel(const ConvArgs a, int tiles_n, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) float tn_smem[];
+  const int tile = xcd_remap((int)blockIdx.x, ntiles);
+  const int mt = tile / tiles_n, nt = tile - mt * tiles_n;
+  const int m0 = mt * TileTN::BM, n0 = nt * TileTN::BN;
+  f32x16 acc[1][2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][n][r] = 0.f;
+  {
+    const PatchA<TileTN, EMAX> pa(a, m0);
+    tn_mainloop<EMAX>(pa, a, n0, tn_smem, acc);
+  }
+  EpiRes<TileTN> er;
+  conv_epilogue_fast<TileTN, false, YSUB>(a, acc, m0, n0, tn_smem, er, false);
+}
+
+static int patch_applies(const ConvArgs& a);
+static bool tn_applies(const ConvArgs& a, int emax) {
+  if ((a.off & CONV_OFF_TN) || emax == 0 || !a.w_frag || (a.off & CONV_OFF_BD) || a.Cout % 128 != 0 || a.pre_scale) return false;
+  if (emax == PATCH_EMAX_S && (a.dbg & 256)) return false;          // (dbg bit 256: the 128-entry-patch layers stay on conv_bdp_kernel: A/B)
+  if ((a.dbg & 1024) || !(a.y_H == a.Ho && a.y_W == a.Wo && a.y_oy == 0 && a.y_ox == 0 && a.y_ld == a.Cout && a.y_coff == 0)) return false;
+  if (a.res && (a.res_stride != 1 || a.res_H != a.Ho || a.res_W != a.Wo)) return false;
+  return (int64_t)a.M * a.Cout * 4 < 0xFFFFFFF0LL;
+}
+
+template <int EMAX>
+static int launch_conv_tn(const ConvArgs& a, hipStream_t st) {
+  constexpr int epi = TileTN::BM * (TileTN::BN + 4) * 4;
+  constexpr int lds = epi > EMAX * 128 ? epi : EMAX * 128;
+  if (allow_dynamic_lds(reinterpret_cast<const void*>(conv_tn_kernel<EMAX, false>), lds)) return -1;
+  if (allow_dynamic_lds(reinterpret_cast<const void*>(conv_tn_kernel<EMAX, true>), lds)) return -1;
+  const int tiles_m = (a.M + TileTN::BM - 1) / TileTN::BM, tiles_n = a.Cout / TileTN::BN;
+  const int64_t ntiles = (int64_t)tiles_m * tiles_n;
+  if (ntiles >= 0x7fffffffLL) return set_error("conv: too many tiles");
+  ConvArgs b = a;
+  b.fd_howo = make_fastdiv(a.Ho * a.Wo);
+  b.fd_wo = make_fastdiv(a.Wo);
+  b.fd_wp = make_fastdiv(a.W + 2);
+  b.fd_rpi = make_fastdiv(a.H + 1);
+  b.epi_fast = 1;
+  if (a.y_sub) hipLaunchKernelGGL((conv_tn_kernel<EMAX, true>), dim3((unsigned)ntiles), dim3(256), lds, st, b, tiles_n, (int)ntiles);
+  else hipLaunchKernelGGL((conv_tn_kernel<EMAX, false>), dim3((unsigned)ntiles), dim3(256), lds, st, b, tiles_n, (int)ntiles);
+  DIF_HIP(hipGetLastError());
+  g_last_kernel = EMAX == PATCH_EMAX_L ? "conv_tn_kernel<64x128,patch168+Bdirect>" : "conv_tn_kernel<64x128,patch128+Bdirect>";
+  return 0;
+}
+
 // conv_t2_kernel's layers: the 8x8-tile patch layers with a SHORT K loop (the long ones have conv_bdp_kernel), weights in
 // fragment order, whole 64-channel column tiles, the lean epilogue's plain geometry (no sub-sampled first output)
 static bool t2_applies(const ConvArgs& a) {
@@ -2435,6 +2579,13 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
     }
     // the deferred-epilogue patch kernel before the pipelined (gather) one: with very many tiles (batch 512 on one lane)
     // the 128-channel 28x28 layers qualify for both
+    if (bd && !pw) {
+      // conv_tn_kernel where conv_bdp_kernel would have run (several tiles per resident block): with fewer tiles the 64 x 64
+      // one-tile-per-block kernel has twice as many blocks to balance (ResNet-50V2's 3x3 layers: 4.93 -> 5.42 ms with it)
+      const int emax_tn = patch_applies(a);
+      if (tn_applies(a, emax_tn) && (conv_bdp_ok(a) || (a.dbg & 512)))
+        return emax_tn == PATCH_EMAX_L ? launch_conv_tn<PATCH_EMAX_L>(a, st) : launch_conv_tn<PATCH_EMAX_S>(a, st);
+    }
     if (bd && !pw && conv_bdp_ok(a)) {
       const int emax = patch_applies(a);
       if (emax == PATCH_EMAX_S) return launch_conv_bdp<T, 3>(a, st);

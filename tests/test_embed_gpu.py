@@ -392,6 +392,39 @@ def test_two_subtile_kernel_equals_plain_kernel(cuda):
         m.close()
 
 
+def test_wide_tile_kernel_equals_deferred_epilogue_kernel(cuda):
+    """The linear-patch 3x3 / stride 1 layers with whole 128-channel column blocks and several tiles per resident block run on
+    conv_tn_kernel (64 pixels x 128 channels per block, a wave = 32 pixels x 64 channels, one whole tile per block); option
+    'tn' = 0 sends them back to conv_bdp_kernel (persistent stream-K, deferred epilogue).  Same products; conv_bdp_kernel
+    splits a tile's K range between blocks and adds the partial sums, so the two agree to float32 rounding through the
+    network's ~50 / ~100 layers, not bit for bit (conv_tn_kernel itself adds in conv_igemm_kernel's order).  IResNet-50 at batch 192
+    (the default dispatch, two lanes), and with 'dbg' bit 512 -- the kernel also where conv_bdp_kernel would not run --
+    IResNet-100 / -50 at batches that leave ragged last tiles, tiles spanning two images and few tiles; ResNet-50V2 and VGG16 for the shortcut / no-shortcut / ReLU epilogues; the
+    sub-sampled first output of a stage's last block."""
+    import torch
+    from deep_insight_face.networks.triplet import DifEmbedder
+    rng = np.random.default_rng(48)
+    for arch, n, dbg in (('iresnet50', 192, 0), ('iresnet100', 37, 512), ('iresnet50', 9, 512), ('resnet', 70, 512), ('vgg16', 5, 512)):
+        x = torch.from_numpy(rng.integers(0, 256, (n, 112, 112, 3), dtype=np.uint8)).cuda()
+        m = DifEmbedder(arch, 'v2', 512, (112, 112, 3), max_batch=n).init_synthetic(15)
+        m.set_input_transform(scale=1 / 255.)
+        m.set_option('dbg', dbg)
+        a = m.embed(x)
+        a2 = m.embed(x)
+        kernels = {k for _, k, _ in m.op_table()}
+        m.set_option('tn', 0)
+        m.set_option('dbg', 0)
+        b = m.embed(x)
+        assert not any(k.startswith('conv_tn_kernel') for _, k, _ in m.op_table())
+        assert torch.equal(a, a2)
+        assert any(k.startswith('conv_tn_kernel') for k in kernels), (arch, kernels)
+        assert float((a - b).abs().max()) <= 5e-6, (arch, n, float((a - b).abs().max()))
+        m.set_option('bdp', 0)                     # ... and against conv_igemm_kernel's patch form (stream-K as well at these sizes)
+        c = m.embed(x)
+        assert float((a - c).abs().max()) <= 5e-6, (arch, n, float((a - c).abs().max()))
+        m.close()
+
+
 def test_stem_kernels_equal_general_kernel(cuda):
     """3-channel first layers run on their own kernels: IResNet's 3x3 and ResNet50V2's 7x7 / stride 2 (64 filters) on
     the MFMA with the input patch in LDS and the true K (stem.hip), YOLOv3-face's 3x3 (32 filters) as a direct
