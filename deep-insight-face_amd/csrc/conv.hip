@@ -2660,7 +2660,7 @@ static int launch_conv_pre_impl(const ConvArgs& a, hipStream_t st) {
   // (the two-term split-bf16 tier: whole tiles from one round of blocks up -- as for conv_tn_kernel, one-tile blocks of the two
   // lanes interleave where persistent grids do not: 47.17 -> 46.52 ms at batch 512, 26.91 -> 26.60 at 256; the three-term tier,
   // power-limited, gains at 512 and loses at 256 and keeps stream-K; dbg bit 2048 forces it for the A/B)
-  if (tiles >= 8 * slots || a.Kpad / BK < SK_MIN_KS || (((BF3 && a.bf_terms == 2) || (a.dbg & 2048)) && tiles >= slots)) {
+  if (tiles >= 8 * slots || a.Kpad / BK < SK_MIN_KS || (((BF3 && a.bf_terms == 2) || (a.dbg & 2048)) && tiles >= slots) || (a.dbg & 4096)) {
     P = tiles;
   } else {
     P = slots;
