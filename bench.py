@@ -548,7 +548,7 @@ def main():
         prof = model.profile(crops)
         forwards[batch] = forwards.get(batch, 0) + 1
         det_ops = det.op_table() if pipe is not None else []
-        is_conv = ('conv_igemm', 'conv_pipe', 'conv_bdp', 'conv_t2', 'conv_pw', 'stem')
+        is_conv = ('conv_', 'stem')                                # every convolution kernel family (conv.hip, stem.hip)
         conv_ms = sum(ms for _, k, _, ms in prof if k.startswith(is_conv))
         conv_flops = sum(2 * macs * batch for _, k, macs, _ in prof if k.startswith(is_conv))
         shares = kernel_shares(prof)

@@ -33,7 +33,7 @@ def main():
         out[k] = {'launches_per_forward': nf.get(k, 0) / forwards,
                   'read_bytes_per_forward': 2 * fetch.get(k, 0) * 1024 / forwards,
                   'write_bytes_per_forward': write.get(k, 0) * 1024 / forwards}
-    conv = [v for k, v in out.items() if k.startswith(('conv_igemm', 'conv_pipe', 'conv_bdp', 'conv_t2', 'conv_pw', 'stem_mfma', 'stem3x3'))]
+    conv = [v for k, v in out.items() if k.startswith(('conv_', 'stem_mfma', 'stem3x3'))]
     tot = {'conv_read_bytes_per_forward': sum(v['read_bytes_per_forward'] for v in conv),
            'conv_write_bytes_per_forward': sum(v['write_bytes_per_forward'] for v in conv)}
     tot['conv_hbm_bytes_per_forward'] = tot['conv_read_bytes_per_forward'] + tot['conv_write_bytes_per_forward']
