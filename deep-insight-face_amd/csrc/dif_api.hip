@@ -74,6 +74,7 @@ int dif_gallery_destroy(dif_gallery* h) {
   Gallery& g = h->g;
   if (g.rows) (void)hipFree(g.rows);
   if (g.rows2) (void)hipFree(g.rows2);
+  if (g.rows1) (void)hipFree(g.rows1);
   if (g.probes2) (void)hipFree(g.probes2);
   if (g.sq) (void)hipFree(g.sq);
   if (g.ninv) (void)hipFree(g.ninv);
@@ -96,12 +97,14 @@ int dif_gallery_set(dif_gallery* h, const float* rows_dev, int64_t n, int64_t in
     DIF_HIP(hipStreamSynchronize(st));
     if (g.rows) DIF_HIP(hipFree(g.rows));
     if (g.rows2) DIF_HIP(hipFree(g.rows2));
+    if (g.rows1) DIF_HIP(hipFree(g.rows1));
+    g.rows1 = nullptr;
     if (g.sq) DIF_HIP(hipFree(g.sq));
     if (g.ninv) DIF_HIP(hipFree(g.ninv));
     g.rows = g.rows2 = g.sq = g.ninv = nullptr;
     g.cap = 0;
     g.n = 0;                                               // an allocation failure below leaves an EMPTY gallery, not dangling rows
-    g.rows2_refused = false;
+    g.rows2_refused = g.rows1_refused = false;
     DIF_HIP(hipMalloc(&g.rows, (size_t)n * g.d * sizeof(float)));
     DIF_HIP(hipMalloc(&g.sq, (size_t)n * sizeof(float)));
     DIF_HIP(hipMalloc(&g.ninv, (size_t)n * sizeof(float)));
@@ -112,7 +115,7 @@ int dif_gallery_set(dif_gallery* h, const float* rows_dev, int64_t n, int64_t in
   }
   g.n = n;
   g.index_base = index_base;
-  g.rows2_valid = false;
+  g.rows2_valid = g.rows1_valid = false;
   if (n == 0) return 0;
   DIF_HIP(hipMemcpyAsync(g.rows, rows_dev, (size_t)n * g.d * sizeof(float), hipMemcpyDeviceToDevice, st));
   return gallery_norms(&g, st);
@@ -136,15 +139,26 @@ int dif_gallery_set_option(dif_gallery* h, const char* key, int value) {
     return 0;
   }
   if (std::string(key) == "filter") {
+    // 0: f32 MFMA on the rows themselves; 1: two-term split-bf16 copy; 2: one-term bf16 copy (a wider net, re-ranked)
+    if (value < 0 || value > 2) return set_error("dif_gallery_set_option: 'filter' takes 0, 1 or 2");
     Gallery& g = h->g;
     g.filter_bf2 = value != 0;
-    if (!g.filter_bf2 && g.rows2) {            // the f32 filter reads the rows themselves: give the copy back
+    g.filter_one = value == 2;
+    const bool drop2 = g.rows2 && value != 1, drop1 = g.rows1 && value != 2;
+    if (drop1 || drop2) {                      // give back the copy the chosen filter does not read
       DIF_HIP(hipDeviceSynchronize());         // a dif_match in flight may still read it
-      DIF_HIP(hipFree(g.rows2));
-      g.rows2 = nullptr;
-      g.rows2_valid = false;
+      if (drop2) {
+        DIF_HIP(hipFree(g.rows2));
+        g.rows2 = nullptr;
+        g.rows2_valid = false;
+      }
+      if (drop1) {
+        DIF_HIP(hipFree(g.rows1));
+        g.rows1 = nullptr;
+        g.rows1_valid = false;
+      }
     }
-    if (g.filter_bf2) g.rows2_refused = false; // switched (back) on: the next dif_gallery_set / dif_match builds the copy
+    if (value) g.rows2_refused = g.rows1_refused = false;   // switched (back) on: the next dif_gallery_set / dif_match builds the copy
     return 0;
   }
   return set_error("dif_gallery_set_option: unknown key '%s'", key);
@@ -155,11 +169,11 @@ int dif_gallery_get_stat(dif_gallery* h, const char* key, int64_t* out, void* st
   Gallery& g = h->g;
   const std::string k(key);
   if (k == "split_copy") {
-    *out = (g.rows2 && g.rows2_valid) ? 1 : 0;
+    *out = ((g.rows2 && g.rows2_valid) || (g.rows1 && g.rows1_valid)) ? 1 : 0;
     return 0;
   }
   if (k == "row_bytes") {                      // device bytes held per gallery row
-    *out = (int64_t)g.d * 4 * (g.rows2 ? 2 : 1) + 8;
+    *out = (int64_t)g.d * 4 * (g.rows2 ? 2 : 1) + (g.rows1 ? (int64_t)g.d * 2 : 0) + 8;
     return 0;
   }
   if (k == "exact_probes") {                   // probes the last dif_match sent to the exact whole-gallery search

@@ -23,7 +23,8 @@ struct Gallery {
   int64_t index_base = 0;   // global index of row 0 (gallery sharded across ranks)
   float* rows = nullptr;    // [n][d]
   float* rows2 = nullptr;   // the same rows as two bf16 planes per K-step of 32, [n][d/32][hi 32 | mid 32] (the filter's operand)
-  float* probes2 = nullptr; // this call's probes in the same form (probe_cap rows)
+  uint16_t* rows1 = nullptr;// the same rows rounded to bf16, [n][d] (the one-term filter's operand: "filter" = 2)
+  float* probes2 = nullptr; // this call's probes in the filter's form (probe_cap rows)
   float* sq = nullptr;      // |g|^2
   float* ninv = nullptr;    // -1/|g|
   // match workspace (csrc/match.hip): per (block, probe) minimum key, candidate count, candidate rows
@@ -46,7 +47,9 @@ struct Gallery {
   struct GalleryFlags* flags = nullptr;   // rows the filter cannot rank (csrc/match.hip), found by gallery_norms
   bool rows2_valid = false;        // rows2 holds the split of the CURRENT rows
   bool rows2_refused = false;      // its allocation failed for this capacity: the f32 filter serves, no retry per call
-  bool filter_bf2 = true;          // the MFMA filter runs on two-term split-bf16 operands (dif_gallery_set_option "filter" = 0: f32)
+  bool rows1_valid = false, rows1_refused = false;   // the same two states for rows1
+  bool filter_one = true;          // "filter" = 2 (default): one bf16 term per operand (match_b1_kernel), a wider net re-ranked; 1: two terms
+  bool filter_bf2 = true;          // the MFMA filter runs on bf16 operands (dif_gallery_set_option "filter" = 0: f32)
   int bd_fill = 1;                 // "bd_fill": blocks of match_bd_kernel per resident slot (development: no effect measured, r04)
   bool no_bd = false;              // dif_gallery_set_option "bd" = 0: the split-bf16 filter stays on match_tile_kernel for every batch
   bool clamp_nan = false;          // report distance 0 / 1 instead of the reference's NaN (dif_gallery_set_option)

@@ -287,19 +287,22 @@ def test_match_near_ties_vs_golden(cuda, golden_dir, metric):
     for lo, hi in ((0, 1), (1, 34), (34, 48)):
         i2, _ = gal.match(probes[lo:hi], metric)
         assert np.array_equal(i2, g['idx%d' % metric][lo:hi])
-    # the same probes three times over and then some (48 -> 160 > 64 probes, ragged against the 128-probe tile): the
-    # B-direct filter kernel (match_bd_kernel, round 4) serves, with its wave-local candidate lists; 'bd' = 0 keeps the batch
-    # on match_tile_kernel.  Every copy of a probe must get the fixture's answer, on either kernel.
+    # the same probes three times over and then some (48 -> 160 > 64 probes, ragged against the 128-probe tile), on the
+    # one-term bf16 filter (match_b1_kernel: the default, also what served the calls above), the two-term filter's B-direct
+    # kernel (match_bd_kernel) and, 'bd' = 0, its match_tile_kernel.  Every copy of a probe must get the fixture's answer.
     rep = np.concatenate([probes, probes, probes, probes[:16]])
     want_rep = np.concatenate([g['idx%d' % metric]] * 3 + [g['idx%d' % metric][:16]])
-    for bd in (1, 0):
+    for flt, bd in ((2, 1), (1, 1), (1, 0)):
+        gal.set_option('filter', flt)
         gal.set_option('bd', bd)
         i5, d5 = gal.match(rep, metric)
-        assert np.array_equal(i5, want_rep), (bd, np.nonzero(i5 != want_rep)[0])
+        assert np.array_equal(i5, want_rep), (flt, bd, np.nonzero(i5 != want_rep)[0])
         assert np.array_equal(d5[:48], dist, equal_nan=True)
+        i4, d4, k4 = gal.match(probes, metric, return_key=True)
+        assert np.array_equal(i4, idx) and np.array_equal(d4, dist, equal_nan=True) and np.array_equal(k4, key)
     gal.set_option('bd', 1)
-    # the filter stage on the f32 MFMA instead of the two-term split-bf16 default: the same answers, bit for bit (the
-    # filter only proposes candidates; the reference arithmetic decides)
+    # the filter stage on the f32 MFMA instead of bf16 operands: the same answers, bit for bit (the filter only
+    # proposes candidates; the reference arithmetic decides)
     gal.set_option('filter', 0)
     i4, d4, k4 = gal.match(probes, metric, return_key=True)
     assert np.array_equal(i4, idx) and np.array_equal(d4, dist, equal_nan=True) and np.array_equal(k4, key)
@@ -363,13 +366,15 @@ def test_match_degenerate_vs_golden(cuda, golden_dir, name):
             assert np.array_equal(dist[~nan].view(np.uint32), want_d[~nan].view(np.uint32))
         elif (~nan).any():
             assert np.abs(dist[~nan].view(np.int32).astype(np.int64) - want_d[~nan].view(np.int32)).max() <= 4
-        # more than 64 probes (the fixture's, repeated): match_bd_kernel and its wave-local epilogue on the same inputs
+        # more than 64 probes (the fixture's, repeated): match_b1_kernel / match_bd_kernel and their wave-local epilogue
         reps = (80 + B - 1) // B + 1
-        i6, d6 = gal.match(np.concatenate([probes] * reps), metric)
-        assert np.array_equal(i6, np.concatenate([want_i] * reps)), (metric, 'bd')
-        assert np.array_equal(np.isnan(d6), np.concatenate([nan] * reps))
-        # ragged groups of probes (other tile shapes), on either filter (split-bf16 default, f32)
-        for flt in (0, 1):
+        for flt in (2, 1):
+            gal.set_option('filter', flt)
+            i6, d6 = gal.match(np.concatenate([probes] * reps), metric)
+            assert np.array_equal(i6, np.concatenate([want_i] * reps)), (metric, 'filter', flt)
+            assert np.array_equal(np.isnan(d6), np.concatenate([nan] * reps))
+        # ragged groups of probes (other tile shapes), on every filter (f32, two-term, one-term)
+        for flt in (0, 1, 2):
             gal.set_option('filter', flt)
             for lo, hi in ((0, 1), (1, 12), (12, B)):
                 i2, _ = gal.match(probes[lo:hi], metric)
@@ -469,14 +474,14 @@ def test_cosine_similarity_matrix(cuda):
 
 
 def test_filter_option_in_any_order(cuda):
-    """the filter's split-bf16 copy doubles the gallery's device memory.  Switching "filter"
-    to 0 -- before OR after the rows are set -- does without it / frees it; switching it back on rebuilds it at
-    the next match; the answers never change."""
+    """ADVICE r03 (medium): the filter's bf16 copy adds to the gallery's device memory (one-term default: + 50 %;
+    two-term "filter" = 1: + 100 %).  Switching "filter" to 0 -- before OR after the rows are set -- does without it /
+    frees it; switching it back on rebuilds it at the next match; the answers never change."""
     from deep_insight_face import oneshot
     gal_np = gi.gallery(5000, seed=91)
     probes, pick = gi.probes_from(gal_np, 70, seed=92)
     g = oneshot.Gallery(gal_np)
-    assert g.stat('split_copy') == 1 and g.stat('row_bytes') == 2 * 2048 + 8
+    assert g.stat('split_copy') == 1 and g.stat('row_bytes') == 2048 + 1024 + 8
     i0, d0 = g.match(probes, 1)
     g.set_option('filter', 0)                       # after the rows: the copy is given back
     assert g.stat('split_copy') == 0 and g.stat('row_bytes') == 2048 + 8
@@ -487,7 +492,12 @@ def test_filter_option_in_any_order(cuda):
     g.set_option('filter', 1)                       # back on: built by the next match, not silently left on f32
     assert g.stat('split_copy') == 0
     i2, d2 = g.match(probes, 1)
-    assert g.stat('split_copy') == 1
+    assert g.stat('split_copy') == 1 and g.stat('row_bytes') == 2 * 2048 + 8
+    g.set_option('filter', 2)                       # the one-term copy replaces the two-term one
+    assert g.stat('split_copy') == 0 and g.stat('row_bytes') == 2048 + 8
+    i4, d4 = g.match(probes, 1)
+    assert g.stat('split_copy') == 1 and g.stat('row_bytes') == 2048 + 1024 + 8
+    assert np.array_equal(i4, pick) and np.array_equal(d4, d0)
     g.set(gal_np[:3000])                            # smaller set inside the capacity: the copy is refreshed
     i3, _ = g.match(probes[pick < 3000], 1)
     for i in (i0, i1, i2):
@@ -502,6 +512,8 @@ def test_filter_option_in_any_order(cuda):
     assert np.array_equal(h.match(probes, 1)[0], pick)
     with pytest.raises(ValueError):
         h.stat('nonsense')
+    with pytest.raises(ValueError):
+        h.set_option('filter', 3)
     h.close()
 
 
@@ -521,11 +533,15 @@ def test_match_bd_kernel_equals_tile_kernel(cuda, G, B):
     probes[B // 3] = -gal_t[5]                                                  # an anti-parallel pair
     g = oneshot.Gallery(gal_t)
     for metric in (0, 1):
+        g.set_option('filter', 2)                   # the default: one-term bf16 filter, match_b1_kernel
+        i2, d2, k2 = g.match(probes, metric, return_key=True)
+        g.set_option('filter', 1)
         g.set_option('bd', 1)
         i1, d1, k1 = g.match(probes, metric, return_key=True)
         g.set_option('bd', 0)
         i0, d0, k0 = g.match(probes, metric, return_key=True)
         assert torch.equal(i1, i0) and torch.equal(d1.view(torch.int32), d0.view(torch.int32)) and torch.equal(k1.view(torch.int32), k0.view(torch.int32))
+        assert torch.equal(i2, i0) and torch.equal(d2.view(torch.int32), d0.view(torch.int32)) and torch.equal(k2.view(torch.int32), k0.view(torch.int32))
         rows = [0, 1, B // 3, B - 1]
         oi, _, _ = od.match(probes[rows].cpu().numpy(), gal_t.cpu().numpy(), metric)
         assert np.array_equal(i1[rows].cpu().numpy(), oi)

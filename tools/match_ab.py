@@ -15,9 +15,10 @@ for G, B in ((1_000_000, 512), (100_000, 256), (125_000, 4096), (1_000_000, 32))
     idx = torch.empty(B, dtype=torch.int64, device='cuda')
     dist = torch.empty(B, dtype=torch.float32, device='cuda')
     res = {}
-    for flt in (0, 1, 2):                               # f32 filter | bf16x2 on match_tile_kernel | bf16x2 on match_bd_kernel
-        G_.set_option('filter', 1 if flt else 0)
-        G_.set_option('bd', 1 if flt == 2 else 0)
+    flagged = {}
+    for flt in (0, 1, 2, 3):                            # f32 filter | bf16x2 on match_tile_kernel | bf16x2 on match_bd_kernel | one-term bf16 on match_b1_kernel
+        G_.set_option('filter', (0, 1, 1, 2)[flt])
+        G_.set_option('bd', 0 if flt == 1 else 1)
         for name, p in (('planted', probes), ('random', rnd)):
             for _ in range(3):
                 G_.match_into(p, 1, idx, dist)
@@ -28,10 +29,13 @@ for G, B in ((1_000_000, 512), (100_000, 256), (125_000, 4096), (1_000_000, 32))
             ev[1].record()
             torch.cuda.synchronize()
             res[(flt, name)] = (ev[0].elapsed_time(ev[1]) / 10, idx.clone())
-    ok = all(torch.equal(res[(0, n)][1], res[(f, n)][1]) for f in (1, 2) for n in ('planted', 'random')) \
+            flagged[(flt, name)] = G_.stat('exact_probes')
+    ok = all(torch.equal(res[(0, n)][1], res[(f, n)][1]) for f in (1, 2, 3) for n in ('planted', 'random')) \
         and torch.equal(res[(2, 'planted')][1], pick)
-    print('G=%d B=%d  f32 filter %.3f / %.3f ms   bf16x2 tile kernel %.3f / %.3f ms   bf16x2 B-direct kernel %.3f / %.3f ms '
-          '(planted / random probes)  same answers: %s' % (G, B, res[(0, 'planted')][0], res[(0, 'random')][0], res[(1, 'planted')][0],
-                                                         res[(1, 'random')][0], res[(2, 'planted')][0], res[(2, 'random')][0], ok), flush=True)
+    print('G=%d B=%d  f32 filter %.3f / %.3f ms   bf16x2 tile kernel %.3f / %.3f ms   bf16x2 B-direct kernel %.3f / %.3f ms   '
+          'one-term bf16 kernel %.3f / %.3f ms (planted / random probes; probes sent to the exact search: %d / %d)  same answers: %s'
+          % (G, B, res[(0, 'planted')][0], res[(0, 'random')][0], res[(1, 'planted')][0], res[(1, 'random')][0],
+             res[(2, 'planted')][0], res[(2, 'random')][0], res[(3, 'planted')][0], res[(3, 'random')][0],
+             flagged[(3, 'planted')], flagged[(3, 'random')], ok), flush=True)
     G_.close()
     del gal
