@@ -78,7 +78,7 @@ int dif_gallery_destroy(dif_gallery* h) {
   if (g.probes2) (void)hipFree(g.probes2);
   if (g.sq) (void)hipFree(g.sq);
   if (g.ninv) (void)hipFree(g.ninv);
-  for (void* p : {(void*)g.part_key, (void*)g.part_cnt, (void*)g.part_idx, (void*)g.eps, (void*)g.best,
+  for (void* p : {(void*)g.part_key, (void*)g.part_cnt, (void*)g.part_idx, (void*)g.eps, (void*)g.eps32, (void*)g.best,
                   (void*)g.best_dist, (void*)g.flagged, (void*)g.nflag, (void*)g.sqmax_bits, (void*)g.hi,
                   (void*)g.pcls, (void*)g.anti_cnt, (void*)g.anti_idx, (void*)g.flags})
     if (p) (void)hipFree(p);

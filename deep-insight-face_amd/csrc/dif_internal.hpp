@@ -34,6 +34,7 @@ struct Gallery {
   size_t part_cap = 0;
   // per probe: error bound of the search key, packed (key, index) winner, its distance, overflow list
   float* eps = nullptr;
+  float* eps32 = nullptr;          // ... and of the f32 re-check the finish stage makes of the filter's candidates
   unsigned long long* best = nullptr;
   float* best_dist = nullptr;
   int* flagged = nullptr;
