@@ -172,6 +172,10 @@ int dif_gallery_get_stat(dif_gallery* h, const char* key, int64_t* out, void* st
     *out = ((g.rows2 && g.rows2_valid) || (g.rows1 && g.rows1_valid)) ? 1 : 0;
     return 0;
   }
+  if (k == "filter_terms") {                   // what the next dif_match's filter stage runs on: 0 f32 rows, 2 / 1 bf16 terms per operand
+    *out = (g.filter_bf2 && g.filter_one && g.rows1 && g.rows1_valid) ? 1 : ((g.filter_bf2 && g.rows2 && g.rows2_valid) ? 2 : 0);
+    return 0;
+  }
   if (k == "row_bytes") {                      // device bytes held per gallery row
     *out = (int64_t)g.d * 4 * (g.rows2 ? 2 : 1) + (g.rows1 ? (int64_t)g.d * 2 : 0) + 8;
     return 0;

@@ -42,14 +42,17 @@ class Gallery:
         return int(N.lib.dif_gallery_size(self._h))
 
     def set_option(self, key, value):
-        """'filter': 0 runs the MFMA filter stage in float32 instead of two-term split-bf16 (same results).
+        """'filter': 2 (default) runs the MFMA filter stage on operands rounded to bf16 once, 1 on two-term split-bf16
+        operands, 0 in float32: the same results (the filter only proposes candidates), different speed and memory.
         'clamp_nan': 1 reports distance 0 / 1 where the reference's distance is NaN (a similarity rounded
         beyond +-1); the default 0 reports NaN like the reference.  The arg-min is unaffected."""
         N.check(N.lib.dif_gallery_set_option(self._h, key.encode(), int(value)), ValueError)
 
     def stat(self, key):
-        """'split_copy': 1 when the filter's bf16 copy of the rows exists (it doubles the gallery's device memory;
-        when it cannot be allocated the float32 filter serves); 'row_bytes': device bytes per row;
+        """'split_copy': 1 when the filter's bf16 copy of the rows exists (+ 50 % device memory for the one-term
+        filter, + 100 % for the two-term one; when it cannot be allocated the float32 filter serves);
+        'filter_terms': bf16 terms per operand the next match's filter runs on (0: float32 rows);
+        'row_bytes': device bytes per row;
         'exact_probes': probes the last match sent to the exact whole-gallery search (synchronises)."""
         v = ctypes.c_int64(0)
         N.check(N.lib.dif_gallery_get_stat(self._h, key.encode(), ctypes.byref(v), N.stream_ptr()), ValueError)
