@@ -256,6 +256,7 @@ struct ConvPwLoader {
 // entries a 64-pixel tile may need (host-checked bound): two instantiations -- 128 entries cover maps up to 14 wide
 // (16 prefetch registers, no spills), 168 entries 28-wide maps (24 registers, 7 spilled: still +3.7 % on those layers)
 constexpr int PATCH_EMAX_S = 128, PATCH_EMAX_L = 168;
+constexpr int PATCH_EMAX_X = 256;   // conv_tn_kernel only (its LDS is set by the epilogue's 33 KB staging tile): maps up to 59 wide
 constexpr int patch_lds_bytes(int emax) { return emax * 128 + 2 * 64 * 128; }
 constexpr int PATCH_PF_TAP = 4;                       // tap of the current slice at which the next patch is requested
 
@@ -2226,7 +2227,8 @@ static int launch_conv_tn(const ConvArgs& a, hipStream_t st) {
   if (a.y_sub) hipLaunchKernelGGL((conv_tn_kernel<EMAX, true>), dim3((unsigned)ntiles), dim3(256), lds, st, b, tiles_n, (int)ntiles);
   else hipLaunchKernelGGL((conv_tn_kernel<EMAX, false>), dim3((unsigned)ntiles), dim3(256), lds, st, b, tiles_n, (int)ntiles);
   DIF_HIP(hipGetLastError());
-  g_last_kernel = EMAX == PATCH_EMAX_L ? "conv_tn_kernel<64x128,patch168+Bdirect>" : "conv_tn_kernel<64x128,patch128+Bdirect>";
+  g_last_kernel = EMAX == PATCH_EMAX_X ? "conv_tn_kernel<64x128,patch256+Bdirect>"
+                                       : (EMAX == PATCH_EMAX_L ? "conv_tn_kernel<64x128,patch168+Bdirect>" : "conv_tn_kernel<64x128,patch128+Bdirect>");
   return 0;
 }
 
@@ -2582,9 +2584,13 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
     if (bd && !pw) {
       // conv_tn_kernel where conv_bdp_kernel would have run (several tiles per resident block): with fewer tiles the 64 x 64
       // one-tile-per-block kernel has twice as many blocks to balance (ResNet-50V2's 3x3 layers: 4.93 -> 5.42 ms with it)
-      const int emax_tn = patch_applies(a);
+      int emax_tn = patch_applies(a);
+      // maps 29 .. 59 wide (YOLOv3's 52 x 52 stage): a 64-pixel tile's patch needs up to 71 + 3 (W + 2) entries -- more than the
+      // other patch kernels' LDS budget holds, inside this one's (the epilogue's staging tile is larger than the patch)
+      if (emax_tn == 0 && patch_shape(a) && patch_entry_bound(a, 64) <= PATCH_EMAX_X && !(a.dbg & 8192)) emax_tn = PATCH_EMAX_X;
       if (tn_applies(a, emax_tn) && (conv_bdp_ok(a) || (a.dbg & 512)))
-        return emax_tn == PATCH_EMAX_L ? launch_conv_tn<PATCH_EMAX_L>(a, st) : launch_conv_tn<PATCH_EMAX_S>(a, st);
+        return emax_tn == PATCH_EMAX_X ? launch_conv_tn<PATCH_EMAX_X>(a, st)
+                                       : (emax_tn == PATCH_EMAX_L ? launch_conv_tn<PATCH_EMAX_L>(a, st) : launch_conv_tn<PATCH_EMAX_S>(a, st));
     }
     if (bd && !pw && conv_bdp_ok(a)) {
       const int emax = patch_applies(a);

@@ -1151,7 +1151,7 @@ int Net::finalize(int mb) {
   lane_split = (opt_lane_split >= 0 ? opt_lane_split : (long_launches ? 0 : 1)) != 0;
   if (nl < 1) nl = 1;
   if (nl > 8) nl = 8;
-  if (max_batch < 64 * nl || !extra_outputs.empty()) nl = 1;
+  if (max_batch < lane_min_images() * nl) nl = 1;
   lanes.assign(nl, Lane());
   DIF_HIP(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
   for (int l = 0; l < nl; ++l) {
@@ -1225,7 +1225,8 @@ const char* Net::kernel_name(const Op& op, int n) const {
 int Net::run_op(const Op& op, Lane& L, const void* xin, int n, int layout, int dtype, float* out, hipStream_t st) {
   auto ptr = [&](int t) -> float* {
     if (t < 0) return nullptr;
-    if (is_output(t)) return out + (int64_t)n * output_offset(t);   // outputs are laid out one after another
+    // outputs are laid out one after another, each for the WHOLE batch: a lane writes its images' part of each
+    if (is_output(t)) return out + (int64_t)L.out_n * output_offset(t) + (int64_t)L.out_start * tensors[t].elems();
     return L.bufs[tensors[root_of(t)].buf];
   };
   switch (op.kind) {
@@ -1434,7 +1435,7 @@ int Net::run_op(const Op& op, Lane& L, const void* xin, int n, int layout, int d
   return 0;
 }
 
-// Forward.  Batches of >= 64 images are split over the lanes: lane 0 runs on the caller's
+// Forward.  Batches of >= lane_min_images() (64 at 112 x 112; 5 frames at 416 x 416) are split over the lanes: lane 0 runs on the caller's
 // stream, the others on internal HIP streams, layer by layer in lock-step order of submission.
 // Every convolution launch fills the chip, so the lanes mostly alternate; what overlaps is each
 // kernel's tail (its last, partly filled round of blocks) with the head of the other lane's
@@ -1448,7 +1449,9 @@ int Net::embed(const void* xin, int n, int layout, int dtype, float* out, hipStr
   if (dtype != DIF_DTYPE_F32 && dtype != DIF_DTYPE_U8) return set_error("dif_net_embed: bad dtype %d", dtype);
 
   const int nl = (int)lanes.size();
-  lanes_active = !(op_ms || nl == 1 || n < 64);
+  lanes_active = !(op_ms || nl == 1 || n < lane_min_images());
+  lanes[0].out_n = n;
+  lanes[0].out_start = 0;
   if (!lanes_active) {
     std::vector<hipEvent_t> ev;
     if (op_ms) {
@@ -1469,7 +1472,6 @@ int Net::embed(const void* xin, int n, int layout, int dtype, float* out, hipStr
   }
 
   const size_t in_bytes = (size_t)in_h * in_w * 3 * (dtype == DIF_DTYPE_U8 ? 1 : 4);
-  const int64_t out_elems = tensors[output_tensor].elems();   // (multi-output nets never take this path)
   std::vector<int> start(nl + 1, 0);
   for (int l = 0; l < nl; ++l) {
     int c = n / nl + (l < n % nl ? 1 : 0);
@@ -1484,8 +1486,9 @@ int Net::embed(const void* xin, int n, int layout, int dtype, float* out, hipStr
       const int c = start[l + 1] - start[l];
       if (c == 0) continue;
       hipStream_t ls = lanes[l].stream ? lanes[l].stream : st;
-      if (run_op(ops[i], lanes[l], static_cast<const char*>(xin) + (size_t)start[l] * in_bytes, c, layout, dtype,
-                 out + (int64_t)start[l] * out_elems, ls))
+      lanes[l].out_n = n;
+      lanes[l].out_start = start[l];
+      if (run_op(ops[i], lanes[l], static_cast<const char*>(xin) + (size_t)start[l] * in_bytes, c, layout, dtype, out, ls))
         return -1;
     }
   }
@@ -1519,6 +1522,8 @@ int Net::embed_clock(const void* xin, int n, int layout, int dtype, float* out, 
   trace_buf = d;
   int rc = 0;
   lanes_active = false;
+  lanes[0].out_n = n;
+  lanes[0].out_start = 0;
   for (size_t i = 0; i < ops.size() && !rc; ++i) rc = run_op(ops[i], lanes[0], xin, n, layout, dtype, out, st);
   trace_buf = nullptr;
   std::vector<unsigned long long> h;

@@ -106,6 +106,12 @@ struct Net {
     return off;
   }
   int64_t output_elems() const { return output_offset(-2); }
+  // images from which a forward is worth splitting over two lanes: 64 at 112 x 112, fewer for larger inputs (the detector)
+  int lane_min_images() const {
+    const int64_t px = (int64_t)in_h * in_w;
+    const int64_t m = (64LL * 112 * 112 + px - 1) / (px > 0 ? px : 1);
+    return m < 2 ? 2 : (m > 64 ? 64 : (int)m);
+  }
   float in_scale = 1.f;
   float in_bias[3] = {0.f, 0.f, 0.f};
   int bgr = 0;
@@ -119,6 +125,7 @@ struct Net {
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
     int cap = 0;
+    int out_n = 0, out_start = 0;   // this forward: images in the whole batch, first image of this lane (where its outputs go)
     std::vector<float*> bufs;
     float* sk_slab = nullptr;
     unsigned* sk_flag = nullptr;

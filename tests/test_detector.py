@@ -131,6 +131,55 @@ def test_yolov3_gpu_vs_oracle(cuda, n, hw):
 
 
 @pytest.mark.gpu
+def test_yolov3_two_lanes_equal_one_lane(cuda, monkeypatch):
+    """The three-output detector takes the two-lane executor as well (round 4: a lane writes its images' part of each of
+    the three maps; the split threshold counts pixels -- 5 frames at 416 x 416, 49 at 128 x 128): the same maps as the
+    single-lane executor up to the kernels' batch-dependent summation splits, for an odd batch too, and a batch below
+    the threshold stays on one lane."""
+    from deep_insight_face.detector.run import yolo_v3_face
+    monkeypatch.delenv('DIF_STREAMS', raising=False)
+    two = yolo_v3_face(1, 128, max_batch=101)
+    two.init_synthetic(2024)
+    monkeypatch.setenv('DIF_STREAMS', '1')
+    one = yolo_v3_face(1, 128, max_batch=101)
+    one.set_weights(two.get_weights())
+    monkeypatch.delenv('DIF_STREAMS')
+    x = _frames(101, 128, seed=9)
+    for n in (101, 64, 3):
+        a, b = two.predict_on_batch(x[:n]), one.predict_on_batch(x[:n])
+        assert [t.shape for t in a] == [(n, 4, 4, 18), (n, 8, 8, 18), (n, 16, 16, 18)]
+        for u, v in zip(a, b):
+            np.testing.assert_allclose(u, v, rtol=1e-4, atol=1e-5 * np.abs(v).max())
+    want = odet.yolov3_forward(x[99:101], two.get_weights())     # the second lane's last images, against the oracle
+    for g, w in zip(two.predict_on_batch(x), want):
+        np.testing.assert_allclose(g[99:101], w, rtol=2e-3, atol=2e-4 * np.abs(w).max())
+
+
+@pytest.mark.gpu
+def test_yolov3_wide_patch_kernel_equals_gather_kernel(cuda):
+    """Maps 29 .. 59 wide (the detector's 52 x 52 stage at 416 x 416) take conv_tn_kernel with a 256-entry halo patch where
+    the launch has several tiles per resident block (batch 64 in the bench); 'dbg' bit 512 sends them there at any batch,
+    bit 8192 keeps them on the per-K-step gather (stream-K there at these tile counts: split sums).  Same products: the three
+    maps agree to float32 rounding carried through 75 layers (2e-5 of the map's largest value; an indexing slip shows as O(1));
+    several frames so that tiles span the image boundary; 44- and 36-wide maps (352, 288) beside the 52-wide one."""
+    from deep_insight_face.detector.run import yolo_v3_face
+    for hw, n in ((416, 2), (352, 3), (288, 2)):
+        net = yolo_v3_face(1, hw, max_batch=n)
+        net.init_synthetic(7)
+        x = _frames(n, hw, seed=hw)
+        net.set_option('dbg', 512)
+        a = net.predict_on_batch(x)
+        kernels = {k for _, k, _ in net.op_table()}
+        assert any(k.startswith('conv_tn_kernel<64x128,patch256') for k in kernels), kernels
+        net.set_option('dbg', 512 + 8192)
+        b = net.predict_on_batch(x)
+        assert not any(k.startswith('conv_tn_kernel<64x128,patch256') for _, k, _ in net.op_table())
+        for u, v in zip(a, b):
+            np.testing.assert_allclose(u, v, rtol=1e-3, atol=2e-5 * np.abs(v).max())
+        net.close()
+
+
+@pytest.mark.gpu
 def test_detection_pipeline_end_to_end(cuda):
     """letterbox -> network -> decode -> NMS through the reference-named entry points, compared with
     the oracle fed with the same (GPU-produced) maps, and with the oracle's own network forward."""
