@@ -53,7 +53,8 @@ def main():
     for src, dst in (('layers_r100.txt', 'r100_b256_layers.txt'), ('layers_r50.txt', 'r50_b256_layers.txt'),
                      ('layers_r100_bf16x2.txt', 'r100_b256_bf16x2_layers.txt'), ('layers_yolov3.txt', 'yolov3_b64_layers.txt'),
                      ('latency.txt', 'latency.txt'), ('batch_sweep.txt', 'batch_sweep.txt'), ('bf_tier_gates.txt', 'bf_tier_gates.txt'),
-                     ('match_ab.txt', 'match_filter_ab.txt'), ('match_pmc_table.txt', 'match_wave_states.txt')):
+                     ('match_ab.txt', 'match_filter_ab.txt'), ('match_pmc_table.txt', 'match_wave_states.txt'),
+                     ('match_traffic.txt', 'match_fabric_traffic.txt')):
         cp(src, R + '_' + src.replace(src, dst))
     # forwards per profiled run, in units of the workload's batch: bench.py reports them (`forwards_in_process`:
     # steps + warmup, the per-layer profile, the warm-up and the stamped forward of the clock measurement, and the
@@ -92,10 +93,10 @@ def main():
                     one['roofline']['frac']))
     # the match filter kernel of the same profiled run: per-launch duration from the stats vs the HIP-event match phase
     for r in csv.DictReader(open(os.path.join(OUT, 'ks_default_1lane/p_kernel_stats.csv'))):
-        if 'match_bd_kernel' in r['Name']:
-            lines.append('match_bd_kernel in that run: %s calls, %.1f us average (kernel-trace stats) vs match phase %.3f ms by HIP events '
-                         '(the phase also holds probe_eps / split2_frag / finish / exact / output)'
-                         % (r['Calls'], float(r['AverageNs']) / 1e3, one['phases_ms']['match']))
+        if 'match_b1_kernel' in r['Name'] or 'match_bd_kernel' in r['Name']:
+            lines.append('%s in that run: %s calls, %.1f us average (kernel-trace stats) vs match phase %.3f ms by HIP events '
+                         '(the phase also holds probe_eps / hi1_frag / finish / exact / output)'
+                         % (r['Name'].split('(')[0].split('::')[-1], r['Calls'], float(r['AverageNs']) / 1e3, one['phases_ms']['match']))
     d = jl(os.path.join(OUT, 'bench_default.json'))
     dp = jl(os.path.join(OUT, 'ks_default.json'))
     lines.append('default workload, default executor (two lanes): un-profiled %.0f faces/s, forward %.2f ms, frac %.4f (b256: '

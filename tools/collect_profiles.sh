@@ -46,5 +46,6 @@ DIF_OPTIONS=dbg=768 python3 tools/bf3_trace.py 256 f32 2> $O/place_r100_f32.txt 
 (for b in 64 128 256 512 1024; do python3 tools/time_embed.py iresnet100 $b 2>/dev/null | tail -1; done; for b in 64 128 256 512 1024 2048; do python3 tools/time_embed.py resnet $b 2>/dev/null | tail -1; done) > $O/batch_sweep.txt &&
 python3 tools/bf_tier_gates.py 256 512 2>/dev/null | grep -v amdgpu > $O/bf_tier_gates.txt &&
 python3 tools/match_ab.py 2>/dev/null | tail -4 > $O/match_ab.txt &&
-(bash tools/pmc_match.sh > /dev/null 2>&1; cp gpurun_out/match_pmc/table.txt $O/match_pmc_table.txt)
+(bash tools/pmc_match.sh > /dev/null 2>&1; cp gpurun_out/match_pmc/table.txt $O/match_pmc_table.txt) &&
+(bash tools/pmc_match_traffic.sh 2>/dev/null | grep "per dif_match" > $O/match_traffic.txt)
 echo "collect rc=$?"
