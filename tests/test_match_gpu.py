@@ -457,6 +457,45 @@ def test_match_exact_search_on_overflow(cuda):
     gal.close()
 
 
+@pytest.mark.parametrize('B', [6, 130])
+def test_one_term_filter_wide_net(cuda, B):
+    """The one-term bf16 filter's proven bound is ~0.008 |q| (two-term: 1.6e-4 |q|).  A cluster of rows whose cosine to the
+    probe differs by 1e-4 .. 3e-3 -- many images of one identity -- lies INSIDE that net and far outside the two-term one:
+    the one-term filter must still return the reference's row (re-ranked among the cluster; the cluster's best row is not
+    the one its bf16 dot ranks first for most probes), with 10 rows per cluster from its lists, with 40 -- in ONE wave row
+    of one tile, more than its list of 13 holds -- from the exact search, and say so in 'exact_probes'; the two-term filter
+    (two or three rows of the cluster inside ITS bound) needs neither for the clusters of 10."""
+    from deep_insight_face import oneshot
+    G = 20_000
+    rng = np.random.default_rng(600 + B)
+    gal_np = gi.gallery(G, seed=61)
+    probes, _ = gi.probes_from(gal_np, B, seed=62)
+    for size in (10, 40):
+        g = gal_np.copy()
+        for b in range(B):
+            rows = 128 * b + 5 + np.arange(size)                                         # one wave row of one tile: one candidate list
+            noise = rng.standard_normal((size, 512)).astype(np.float32)
+            noise -= (noise @ probes[b])[:, None] * probes[b][None]                      # orthogonal to the probe
+            noise /= np.linalg.norm(noise, axis=1, keepdims=True)
+            t = np.sqrt(2 * rng.uniform(1e-4, 3e-3, size)).astype(np.float32)            # cos = 1 / sqrt(1 + t^2): 1e-4 .. 3e-3 below 1, evenly
+            g[rows] = gi._unit(probes[b][None] + t[:, None] * noise)
+        with np.errstate(invalid='ignore'):
+            want = {m: od.match(probes, g, m)[0] for m in (0, 1)}
+        gal = oneshot.Gallery(g)
+        for m in (0, 1):
+            gal.set_option('filter', 2)
+            i2, d2 = gal.match(probes, m)
+            flagged2 = gal.stat('exact_probes')
+            gal.set_option('filter', 1)
+            i1, d1 = gal.match(probes, m)
+            flagged1 = gal.stat('exact_probes')
+            assert np.array_equal(i2, want[m]) and np.array_equal(i1, want[m]), (size, m)
+            assert np.array_equal(d2, d1)
+            assert size == 40 or flagged1 == 0          # (40 rows 7e-5 apart can chain past its lists of 8 too: a running minimum that creeps down never restarts one)
+            assert (flagged2 == 0) if size == 10 else (flagged2 > 0), (size, m, flagged2)
+        gal.close()
+
+
 def test_cosine_similarity_matrix(cuda):
     """the all-pairs cosine matrix of common/losses.py:39-40 as an entry point."""
     from deep_insight_face import oneshot
