@@ -117,18 +117,22 @@ int dif_gallery_destroy(dif_gallery* g);
  * per-row norms; index_base = global index of row 0 (gallery row-sharded over ranks) */
 int dif_gallery_set(dif_gallery* g, const float* rows_dev, int64_t n, int64_t index_base, void* stream);
 int64_t dif_gallery_size(const dif_gallery* g);
-/* options.  "filter": 1 (default) the MFMA stage of dif_match -- a candidate filter with a proven error bound; the
- * winner is chosen on the reference's own float32 arithmetic either way -- runs on two-term split-bf16 copies of the
- * gallery and the probes (three bf16 MFMAs per 16 k), 0 on the f32 MFMA; results are identical.  The split copy of the
- * gallery doubles its device memory (d * 4 bytes per row more).  It is built by dif_gallery_set, or by the first
- * dif_match after the option was switched on; setting "filter" to 0 frees it (in either order with dif_gallery_set);
- * when it cannot be allocated the f32 filter serves and nothing fails (dif_gallery_get_stat "split_copy" tells).
+/* options.  "filter": what the MFMA stage of dif_match -- a candidate filter with a proven error bound; the winner
+ * is chosen on the reference's own float32 arithmetic whatever it is -- runs on.  2 (default): the gallery rows and the
+ * probes rounded to bf16 once (one bf16 MFMA per 16 k; bound ~0.008 |q|: a few rows per probe re-ranked; the copy
+ * costs d * 2 bytes per row); 1: two-term split-bf16 copies (three MFMAs per 16 k; bound 1.6e-4 |q|; d * 4 bytes per
+ * row); 0: the f32 MFMA on the rows themselves (no copy).  Results are identical.  Embedding sizes that are not
+ * multiples of 64, or below 128, take the two-term form under 2 as well.  The copy is built by dif_gallery_set, or by
+ * the first dif_match after the option changed; changing it frees the copy the new filter does not read (in either
+ * order with dif_gallery_set); when a copy cannot be allocated the f32 filter serves and nothing fails
+ * (dif_gallery_get_stat "split_copy" / "filter_terms" tell).
  * "clamp_nan": 0 (default) dif_match reports NaN where the reference's distance is NaN; 1 reports the
  * distance of the similarity clamped to [-1, 1] instead (0 for a similarity rounded above 1, 1 below -1).  The
  * arg-min is the reference's either way. */
 int dif_gallery_set_option(dif_gallery* g, const char* key, int value);
 /* read-outs (no reference counterpart; for capacity planning and tests).  "split_copy": 1 when the filter's bf16 copy
- * of the current rows exists; "row_bytes": device bytes held per gallery row; "exact_probes": how many probes the
+ * of the current rows exists; "filter_terms": bf16 terms per operand the next dif_match's filter runs on (1 or 2; 0 = the f32 rows);
+ * "row_bytes": device bytes held per gallery row; "exact_probes": how many probes the
  * last dif_match on `stream` sent to the exact whole-gallery search (synchronises the stream). */
 int dif_gallery_get_stat(dif_gallery* g, const char* key, int64_t* out, void* stream);
 /* top-1 search of n probes [n][d]: idx_out_dev[n] = np.argmin over the reference's float32 distances
