@@ -643,7 +643,9 @@ struct PatchDma {
     }
   }
   __device__ __forceinline__ void issue(int cblk, char* staging) const {
-    const int wave = threadIdx.x >> 6;
+    // (scalar: the DMA's LDS addresses go to M0 -- as a vector value the eight destinations were hoisted out of the slice loop,
+    // spilled, and every reload, `s_waitcnt vmcnt(0)` behind it, waited for the pieces and B fragments already in flight)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));                          // keeps the offsets from being hoisted out of the K loop (and spilled)
 #pragma unroll
@@ -716,7 +718,9 @@ struct PatchDma2D {
     }
   }
   __device__ __forceinline__ void issue(int cblk, char* staging) const {
-    const int wave = threadIdx.x >> 6;
+    // (scalar: the DMA's LDS addresses go to M0 -- as a vector value the eight destinations were hoisted out of the slice loop,
+    // spilled, and every reload, `s_waitcnt vmcnt(0)` behind it, waited for the pieces and B fragments already in flight)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));                          // recompute the offsets per slice (see PatchDma)
 #pragma unroll
