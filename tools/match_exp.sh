@@ -1,6 +1,6 @@
 #!/bin/bash
 # development: kernel-trace stats of dif_match under the timing-experiment builds of the one-term filter kernel
-# (lib/libdif_eN.so = match.hip with -DB1_EXP=N; results of those builds are invalid, only the kernel's duration counts)
+# (lib/libdif_eN.so = match.hip with -DB1_EXP=N, built by tools/build_variant.sh; results of those builds are invalid, only the kernel durations count)
 cd /tmp && export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/match_exp
 mkdir -p $out
