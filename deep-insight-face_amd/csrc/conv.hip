@@ -1080,6 +1080,8 @@ struct NoLoader {};   // B operand of the B-direct kernels: fetched by the mainl
 #undef IGEMM_KERNEL_NAME
 #undef IGEMM_BF_MAINLOOP
 
+#include "conv_splitk.hpp"
+
 // ------------------------------------------------------------------------------------------
 // Software-pipelined variant for layers with a SHORT K loop and several tiles per resident block
 // (the 1x1 layers of the bottleneck networks, 3x3 layers with 64 input channels).
@@ -2376,8 +2378,61 @@ static int launch_conv_pw(const ConvArgs& a, hipStream_t st) {
   return a.pre_scale ? launch_conv_pw_t<T, true>(a, st) : launch_conv_pw_t<T, false>(a, st);
 }
 
+// ---- the small-batch split-K path (conv_splitk.hpp)
+// Few tiles with a long K loop: S splits per tile so that the grid is about two blocks per CU, each share at least
+// SK2_MIN_KS K-steps; 0 = the path does not apply.  A pure function of the layer's shape and the batch (deterministic sums).
+constexpr int SK2_MIN_KS = 4;
+static int sk2_plan(const ConvArgs& a) {
+  if ((a.off & CONV_OFF_SK2) || a.trace) return 0;
+  const int64_t tiles = ((a.M + 63) / 64) * (int64_t)((a.Cout + 63) / 64);
+  const int KS = a.Kpad / BK;
+  const int64_t target = 2 * (int64_t)num_cus();
+  if (tiles >= target || KS < 2 * SK2_MIN_KS) return 0;
+  int64_t S = (target + tiles - 1) / tiles;
+  if (S > KS / SK2_MIN_KS) S = KS / SK2_MIN_KS;
+  const int64_t cap = (int64_t)a.sk_max_blocks * (int64_t)conv_slab_floats() / 4096;   // slabs the workspace holds
+  if (tiles * S > cap) S = cap / tiles;
+  return S >= 2 ? (int)S : 0;
+}
+
+template <bool PRE, int AM>
+static int launch_conv_sk(const ConvArgs& a, int S, hipStream_t st) {
+  using T = Tile<1, 1>;
+  void (*kern)(const ConvArgs, int, int, int) = conv_sk_kernel<T, PRE, AM>;
+  if (allow_dynamic_lds(reinterpret_cast<const void*>(kern), T::LDS_BYTES)) return -1;
+  const int tiles_m = (a.M + 63) / 64, tiles_n = (a.Cout + 63) / 64;
+  ConvArgs b = a;
+  b.fd_howo = make_fastdiv(a.Ho * a.Wo);
+  b.fd_wo = make_fastdiv(a.Wo);
+  b.fd_cin = make_fastdiv(a.Cin);
+  b.fd_kw = make_fastdiv(a.KW);
+  b.fd_taps = make_fastdiv(a.KH * a.KW);
+  if (a.k_order == 1 && a.Cin % BK != 0) return set_error("conv: channel-block-major K order needs Cin %% 32 == 0");
+  const int pairs = tiles_n * S;
+  const unsigned grid = (unsigned)(((pairs + 7) / 8) * 8 * tiles_m);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(T::NT), T::LDS_BYTES, st, b, S, tiles_m, tiles_n);
+  DIF_HIP(hipGetLastError());
+  hipLaunchKernelGGL(conv_sk_reduce_kernel, dim3((unsigned)(tiles_m * tiles_n * 16)), dim3(64), 0, st, b, S, tiles_n);
+  DIF_HIP(hipGetLastError());
+  {                                                         // interned: Op::ran_kernel keeps the pointer
+    static std::mutex mu;
+    static std::set<std::string> names;
+    std::lock_guard<std::mutex> lock(mu);
+    g_last_kernel = names.insert(std::string("conv_sk_kernel<64x64,") + am_form(AM) + (PRE ? ",preact" : "") + ",S=" +
+                                 std::to_string(S) + ">+reduce").first->c_str();
+  }
+  return 0;
+}
+
 template <class T>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
+  if constexpr (T::BM == 64 && T::BN == 64) {
+    if (const int S = sk2_plan(a)) {
+      const bool pw1 = a.KH == 1 && a.KW == 1 && a.pad_t == 0 && a.pad_l == 0 && a.Cin % BK == 0;
+      if (pw1) return a.pre_scale ? launch_conv_sk<true, 1>(a, S, st) : launch_conv_sk<false, 1>(a, S, st);
+      return a.pre_scale ? launch_conv_sk<true, 0>(a, S, st) : launch_conv_sk<false, 0>(a, S, st);
+    }
+  }
   // (LDS-DMA operand staging was +1..5 % on the plain GEMM microbenchmark but -1.2 % inside this kernel -- interleaved
   // A/B, both networks -- so operands are staged through registers.)
   // 1x1 / no padding / whole 32-channel K-steps: the pointwise loader

@@ -29,6 +29,24 @@ static int check_metric(int metric) {
 
 using namespace dif;
 
+template <class P>
+static int regrow(P** p, size_t keep_bytes, size_t new_bytes, hipStream_t st) {
+  P* q = nullptr;
+  DIF_HIP(hipMalloc(&q, new_bytes));
+  if (*p && keep_bytes) {
+    hipError_t e = hipMemcpyAsync(q, *p, keep_bytes, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+      (void)hipFree(q);
+      return set_error("dif_gallery_reserve: copy failed: %s", hipGetErrorString(e));
+    }
+  }
+  if (*p) DIF_HIP(hipFree(*p));
+  *p = q;
+  return 0;
+}
+
+
 struct dif_gallery {
   Gallery g;
 };
@@ -121,7 +139,72 @@ int dif_gallery_set(dif_gallery* h, const float* rows_dev, int64_t n, int64_t in
   return gallery_norms(&g, st);
 }
 
+int dif_gallery_reserve(dif_gallery* h, int64_t capacity, void* stream) {
+  if (!h) return set_error("dif_gallery_reserve: null handle");
+  if (capacity > 0x7ffffff0LL) return set_error("dif_gallery_reserve: at most 2^31-16 rows per shard");
+  Gallery& g = h->g;
+  if (capacity <= g.cap) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  DIF_HIP(hipStreamSynchronize(st));
+  const size_t c = (size_t)capacity, n = (size_t)g.n, d = (size_t)g.d;
+  if (regrow(&g.rows, n * d * 4, c * d * 4, st)) return -1;
+  if (regrow(&g.sq, n * 4, c * 4, st)) return -1;
+  if (regrow(&g.ninv, n * 4, c * 4, st)) return -1;
+  // the filter's copy: moved when it fits, otherwise dropped (the next dif_match rebuilds it, or the f32 filter serves)
+  if (g.rows1) {
+    uint16_t* q = nullptr;
+    if (hipMalloc(&q, c * d * 2) == hipSuccess) {
+      if (g.rows1_valid && n) {
+        DIF_HIP(hipMemcpyAsync(q, g.rows1, n * d * 2, hipMemcpyDeviceToDevice, st));
+        DIF_HIP(hipStreamSynchronize(st));
+      }
+    } else {
+      (void)hipGetLastError();
+      g.rows1_valid = false;
+    }
+    DIF_HIP(hipFree(g.rows1));
+    g.rows1 = q;
+  }
+  if (g.rows2) {
+    float* q = nullptr;
+    if (hipMalloc(&q, c * d * 4) == hipSuccess) {
+      if (g.rows2_valid && n) {
+        DIF_HIP(hipMemcpyAsync(q, g.rows2, n * d * 4, hipMemcpyDeviceToDevice, st));
+        DIF_HIP(hipStreamSynchronize(st));
+      }
+    } else {
+      (void)hipGetLastError();
+      g.rows2_valid = false;
+    }
+    DIF_HIP(hipFree(g.rows2));
+    g.rows2 = q;
+  }
+  g.rows1_refused = g.rows2_refused = false;
+  g.cap = capacity;
+  return 0;
+}
+
+int dif_gallery_update(dif_gallery* h, const float* rows_dev, int64_t n, int64_t first_row, void* stream) {
+  if (!h) return set_error("dif_gallery_update: null handle");
+  if (n < 0 || first_row < 0) return set_error("dif_gallery_update: negative row count or position");
+  if (n > 0 && !rows_dev) return set_error("dif_gallery_update: null rows");
+  Gallery& g = h->g;
+  if (first_row > g.n)
+    return set_error("dif_gallery_update: first_row %lld would leave a gap behind the gallery's %lld rows", (long long)first_row,
+                     (long long)g.n);
+  if (first_row + n > g.cap)
+    return set_error("dif_gallery_update: rows [%lld, %lld) exceed the capacity of %lld rows (dif_gallery_reserve grows it)",
+                     (long long)first_row, (long long)(first_row + n), (long long)g.cap);
+  if (n == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  DIF_HIP(hipMemcpyAsync(g.rows + (size_t)first_row * g.d, rows_dev, (size_t)n * g.d * sizeof(float), hipMemcpyDeviceToDevice, st));
+  const int64_t old_n = g.n;
+  if (first_row + n > g.n) g.n = first_row + n;
+  return gallery_update_rows(&g, first_row, n, old_n, st);
+}
+
 int64_t dif_gallery_size(const dif_gallery* h) { return h ? h->g.n : 0; }
+int64_t dif_gallery_capacity(const dif_gallery* h) { return h ? h->g.cap : 0; }
 
 int dif_gallery_set_option(dif_gallery* h, const char* key, int value) {
   if (!h || !key) return set_error("dif_gallery_set_option: null argument");

@@ -24,7 +24,8 @@ struct Gallery {
   float* rows = nullptr;    // [n][d]
   float* rows2 = nullptr;   // the same rows as two bf16 planes per K-step of 32, [n][d/32][hi 32 | mid 32] (the filter's operand)
   uint16_t* rows1 = nullptr;// the same rows rounded to bf16, [n][d] (the one-term filter's operand: "filter" = 2)
-  float* probes2 = nullptr; // this call's probes in the filter's form (probe_cap rows)
+  float* probes2 = nullptr; // this call's probes in the filter's form (probes2_cap rows of d floats)
+  size_t probes2_cap = 0;
   float* sq = nullptr;      // |g|^2
   float* ninv = nullptr;    // -1/|g|
   // match workspace (csrc/match.hip): per (block, probe) minimum key, candidate count, candidate rows
@@ -58,6 +59,7 @@ struct Gallery {
 
 int gallery_norms(Gallery* g, hipStream_t st);
 int gallery_split_copy(Gallery* g, hipStream_t st);   // (re)builds rows2 when the option asks for it; never fatal
+int gallery_update_rows(Gallery* g, int64_t first, int64_t count, int64_t old_n, hipStream_t st);   // after rows [first, first+count) changed
 int match_run(Gallery* g, const float* probes, int B, int metric, int64_t* idx_out, float* dist_out,
               float* key_out, hipStream_t st);
 int pairwise_run(const float* e1, int64_t n1, const float* e2, int64_t n2, int D, int metric, float* out,

@@ -894,6 +894,7 @@ int Net::set_option(const char* key, int value) {
   if (!strcmp(key, "bd")) return flag(CONV_OFF_BD);
   if (!strcmp(key, "t2")) return flag(CONV_OFF_T2);
   if (!strcmp(key, "tn")) return flag(CONV_OFF_TN);
+  if (!strcmp(key, "sk2")) return flag(CONV_OFF_SK2);
   if (!strcmp(key, "pw")) {                                 // conv_pw_kernel is OFF by default: the bit means "on" for this family
     conv_off = value ? (conv_off | CONV_OFF_PW) : (conv_off & ~CONV_OFF_PW);
     return 0;

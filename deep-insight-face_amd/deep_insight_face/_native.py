@@ -45,6 +45,9 @@ SIGNATURES = {
     'dif_gallery_destroy': (c_int, [c_void_p]),
     'dif_gallery_set': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     'dif_gallery_size': (c_int64, [c_void_p]),
+    'dif_gallery_update': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    'dif_gallery_reserve': (c_int, [c_void_p, c_int64, c_void_p]),
+    'dif_gallery_capacity': (c_int64, [c_void_p]),
     'dif_gallery_set_option': (c_int, [c_void_p, c_char_p, c_int]),
     'dif_gallery_get_stat': (c_int, [c_void_p, c_char_p, P(c_int64), c_void_p]),
     'dif_match': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -38,6 +38,32 @@ class Gallery:
         N.check(N.lib.dif_gallery_set(self._h, N.ptr(g), g.shape[0], int(index_base), N.stream_ptr()))
         torch.cuda.current_stream().synchronize()   # g may be a temporary: the copy must have landed
 
+    def update(self, embeddings, first_row=None):
+        """Enrol incrementally: overwrite rows [first_row, first_row + k) or, with first_row None (or == len(self)),
+        append -- O(k) on the device (`set` is a pass over the whole gallery).  Appending beyond the capacity grows it
+        by half (one reallocation + copy)."""
+        g, _ = N.to_device_f32(embeddings, self._dev)
+        if g.dim() == 1:
+            g = g[None, :]
+        if g.dim() != 2 or g.shape[1] != self.emd_size:
+            raise ValueError('rows must be [k, %d], got %s' % (self.emd_size, tuple(g.shape)))
+        n = len(self)
+        first_row = n if first_row is None else int(first_row)
+        if first_row < 0 or first_row > n:
+            raise ValueError('first_row %d outside [0, %d]' % (first_row, n))
+        need = first_row + g.shape[0]
+        if need > self.capacity:
+            self.reserve(max(need, self.capacity + self.capacity // 2))
+        N.check(N.lib.dif_gallery_update(self._h, N.ptr(g), g.shape[0], first_row, N.stream_ptr()), ValueError)
+        torch.cuda.current_stream().synchronize()   # g may be a temporary: the copy must have landed
+
+    def reserve(self, capacity):
+        N.check(N.lib.dif_gallery_reserve(self._h, int(capacity), N.stream_ptr()))
+
+    @property
+    def capacity(self):
+        return int(N.lib.dif_gallery_capacity(self._h))
+
     def __len__(self):
         return int(N.lib.dif_gallery_size(self._h))
 

@@ -60,11 +60,21 @@ class ShardedGallery:
     """Row shard of a gallery plus the two collectives around the local match."""
 
     def __init__(self, shard_rows, index_base, group=None, match_fn=None, merge_fn=None, gallery=None,
-                 force_collectives=False):
+                 force_collectives=False, check_batch='always'):
         """`force_collectives`: with a world of ONE rank the two all-gathers and the merge are short-cut (they
         would move a rank's data to itself); True runs them all the same -- the whole N > 1 branch over the real
         backend on a single GPU (tests/test_parallel_gpu.py::test_rccl_single_rank_runs_the_sharded_branch).
-        Needs an initialised process group."""
+        Needs an initialised process group.
+        `check_batch`: every rank must bring the SAME number of probes b to a step (all_gather_into_tensor sizes its
+        buffers from this rank's b: a ragged last batch on one rank would otherwise hang or gather garbage).
+        'always' (default) compares the ranks' b before every step -- one 8-byte all-gather and a host read, raising
+        ValueError on EVERY rank when they differ; 'first' only when this rank meets a (b, d) shape for the first
+        time (no host read in a steady serving loop: what bench.py times; a rank whose shape is cached does not take
+        part, so it protects the first step of a shape only); 'never' trusts the caller."""
+        if check_batch not in ('always', 'first', 'never'):
+            raise ValueError("check_batch must be 'always', 'first' or 'never'")
+        self.check_batch = check_batch
+        self.phase_events = None      # bench.py: a list to which every step appends its five CUDA events (see match)
         self.group = group
         self.force = bool(force_collectives)
         if self.force and not dist.is_initialized():
@@ -91,6 +101,18 @@ class ShardedGallery:
         dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
         return out
 
+    def _check_same_batch(self, b, device, first_time):
+        """Raises ValueError on every rank when the ranks' probe counts differ (see __init__: check_batch)."""
+        if self.world == 1 or self.check_batch == 'never' or (self.check_batch == 'first' and not first_time):
+            return
+        mine = torch.tensor([int(b)], dtype=torch.int64, device=device)
+        sizes = torch.empty((self.world,), dtype=torch.int64, device=device)
+        dist.all_gather_into_tensor(sizes, mine, group=self.group)
+        sizes = [int(v) for v in sizes.cpu().tolist()]
+        if any(v != sizes[0] for v in sizes):
+            raise ValueError('ShardedGallery.match: every rank must bring the same number of probes per step, got %s '
+                             '(pad the ragged last batch, or drop it, on all ranks alike)' % sizes)
+
     def match(self, local_embeddings, distance_metric=1, copy=True):
         """Steps 2-5: returns (idx[R*b] int64 global, dist[R*b] float32), identical on every rank.
         `local_embeddings`: [b, emd_size], NumPy or torch on any device / float dtype / strides (converted to a
@@ -109,24 +131,44 @@ class ShardedGallery:
         b, d = local_embeddings.shape
         key = (b, d, local_embeddings.device)
         buf = self._bufs.get(key)
+        self._check_same_batch(b, local_embeddings.device, buf is None)
         if buf is None:
             buf = self._bufs[key] = _StepBuffers(self.world, b, d, local_embeddings.device)
         B = self.world * b
+        evs = None
+        if self.phase_events is not None:                     # [start, embeddings gathered, matched, records gathered, merged]
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+            self.phase_events.append(evs)
+            evs[0].record()
         probes = self.all_gather_embeddings(local_embeddings, buf.probes)
+        if evs:
+            evs[1].record()
         k, dd, ix = buf.record(B)
         if self.world == 1 and not self.force:
             self.gallery.match_into(probes, distance_metric, buf.out_idx, buf.out_dist)
+            if evs:
+                for e in evs[2:]:
+                    e.record()
         else:
             self.gallery.match_into(probes, distance_metric, ix, dd, k)
+            if evs:
+                evs[2].record()
             dist.all_gather_into_tensor(buf.packed.view(-1), buf.local, group=self.group)
+            if evs:
+                evs[3].record()
             N.check(N.lib.dif_match_merge_packed(N.ptr(buf.packed), self.world, B, N.ptr(buf.out_idx),
                                                  N.ptr(buf.out_dist), N.stream_ptr()))
+            if evs:
+                evs[4].record()
         if copy:
             return buf.out_idx.clone(), buf.out_dist.clone()
         return buf.out_idx, buf.out_dist
 
     def _match_injected(self, local_embeddings, distance_metric):
         """The same exchange with stand-in compute (CPU tests over gloo: the HIP kernels need a GPU)."""
+        shape = tuple(local_embeddings.shape)
+        self._check_same_batch(shape[0], local_embeddings.device, shape not in self._bufs)
+        self._bufs.setdefault(shape, True)
         probes = self.all_gather_embeddings(local_embeddings)
         key, idx, d = self._match(self.gallery, probes, distance_metric)
         if self.world == 1 and not self.force:

@@ -117,6 +117,17 @@ int dif_gallery_destroy(dif_gallery* g);
  * per-row norms; index_base = global index of row 0 (gallery row-sharded over ranks) */
 int dif_gallery_set(dif_gallery* g, const float* rows_dev, int64_t n, int64_t index_base, void* stream);
 int64_t dif_gallery_size(const dif_gallery* g);
+/* incremental enrolment (no reference counterpart: the reference keeps its "database" as a Python dict of encodings,
+ * predictions.py:98-126 `verify(image, identity, database, ...)`, and re-reads it per call).
+ * dif_gallery_update: overwrite rows [first_row, first_row + n) with `n` rows from device memory, or append them
+ *   (first_row == dif_gallery_size; first_row beyond it would leave a gap and fails); the rows must fit the
+ *   capacity.  Costs O(n): only those rows' norms and filter copy are recomputed (dif_gallery_set is one pass over
+ *   the whole gallery).  The match results are exactly those of a dif_gallery_set with the resulting rows.
+ * dif_gallery_reserve: grow the capacity (rows are kept; never shrinks); dif_gallery_set sizes it to its `n`.
+ * dif_gallery_capacity: rows the handle can hold without reallocating. */
+int dif_gallery_update(dif_gallery* g, const float* rows_dev, int64_t n, int64_t first_row, void* stream);
+int dif_gallery_reserve(dif_gallery* g, int64_t capacity, void* stream);
+int64_t dif_gallery_capacity(const dif_gallery* g);
 /* options.  "filter": what the MFMA stage of dif_match -- a candidate filter with a proven error bound; the winner
  * is chosen on the reference's own float32 arithmetic whatever it is -- runs on.  2 (default): the gallery rows and the
  * probes rounded to bf16 once (one bf16 MFMA per 16 k; bound ~0.008 |q|: a few rows per probe re-ranked; the copy

@@ -42,9 +42,13 @@ def build(arch, head, emd, max_batch=8):
                                              ('iresnet100', 'v2', 512, 2), ('vgg16', 'v2', 512, 3),
                                              ('mobilenet', 'v2', 512, 5), ('mobilenet', 'v3', 512, 2),
                                              ('mobilenet', 'v1', 128, 2), ('resnet', 'sv2', 128, 3),
-                                             ('vgg16', 'sv2', 128, 2)])
+                                             ('vgg16', 'sv2', 128, 2),
+                                             # the reference's own call shapes: ONE image per call
+                                             # (predictions.py:152-156) and batch 12 (scripts/insight_face.py:112)
+                                             ('resnet', 'v2', 512, 1), ('resnet', 'v2', 512, 12),
+                                             ('iresnet100', 'v2', 512, 1), ('iresnet100', 'v2', 512, 12)])
 def test_embed_vs_oracle(cuda, arch, head, emd, n):
-    model, p = build(arch, head, emd)
+    model, p = build(arch, head, emd, max_batch=max(8, n))
     x = scaled(crops_u8(n))
     got = model.predict_on_batch(x)
     want = nets.embed(x, p, arch, emd, head)
@@ -260,6 +264,7 @@ def test_pipelined_kernel_equals_plain_kernel(cuda, monkeypatch):
         x = torch.from_numpy(rng.integers(0, 256, (n,) + shape, dtype=np.uint8)).cuda()
         m = DifEmbedder(arch, head, emd, shape, max_batch=n).init_synthetic(5)
         m.set_input_transform(scale=1 / 255.)
+        m.set_option('sk2', 0)                 # compare the two families themselves (round 5's split-K path would take the small layers)
         m.set_option('pipe', 1)
         a = m.embed(x)
         a2 = m.embed(x)
@@ -291,6 +296,7 @@ def test_deferred_epilogue_kernel_equals_plain_kernel(cuda, monkeypatch):
         x = torch.from_numpy(rng.integers(0, 256, (n, 112, 112, 3), dtype=np.uint8)).cuda()
         m = DifEmbedder(arch, 'v2', 512, (112, 112, 3), max_batch=n).init_synthetic(11)
         m.set_input_transform(scale=1 / 255.)
+        m.set_option('sk2', 0)                 # (the small-batch split-K path would take these layers at these batches)
         m.set_option('bdp', 2)
         a = m.embed(x)
         a2 = m.embed(x)
@@ -317,6 +323,7 @@ def test_lean_epilogue_equals_general_epilogue(cuda):
         x = torch.from_numpy(rng.integers(0, 256, (n, 112, 112, 3), dtype=np.uint8)).cuda()
         m = DifEmbedder(arch, 'v2', 512, (112, 112, 3), max_batch=n, compute=compute).init_synthetic(12)
         m.set_input_transform(scale=1 / 255.)
+        m.set_option('sk2', 0)
         m.set_option('bdp', 0)                 # keep the 3x3 layers on conv_igemm_kernel, whose epilogue this is
         a = m.embed(x)
         m.set_option('dbg', 1024)
@@ -343,6 +350,7 @@ def test_pointwise_kernel_equals_general_kernels(cuda):
         x = torch.from_numpy(rng.integers(0, 256, (n, 112, 112, 3), dtype=np.uint8)).cuda()
         m = DifEmbedder(arch, 'v2', 512, (112, 112, 3), max_batch=n).init_synthetic(13)
         m.set_input_transform(scale=1 / 255.)
+        m.set_option('sk2', 0)                 # compare the two families themselves (round 5's split-K path would take the small layers)
         m.set_option('pw', 1)                      # off by default (slower inside the two-lane executor: r04_ablation item 3)
         a = m.embed(x)
         a2 = m.embed(x)
@@ -380,6 +388,7 @@ def test_two_subtile_kernel_equals_plain_kernel(cuda):
         x = torch.from_numpy(rng.integers(0, 256, (n, 112, 112, 3), dtype=np.uint8)).cuda()
         m = DifEmbedder(arch, 'v2', 512, (112, 112, 3), max_batch=n).init_synthetic(14)
         m.set_input_transform(scale=1 / 255.)
+        m.set_option('sk2', 0)                 # compare the two families themselves (round 5's split-K path would take the small layers)
         a = m.embed(x)
         a2 = m.embed(x)
         kernels = {k for _, k, _ in m.op_table()}
@@ -408,6 +417,7 @@ def test_wide_tile_kernel_equals_deferred_epilogue_kernel(cuda):
         x = torch.from_numpy(rng.integers(0, 256, (n, 112, 112, 3), dtype=np.uint8)).cuda()
         m = DifEmbedder(arch, 'v2', 512, (112, 112, 3), max_batch=n).init_synthetic(15)
         m.set_input_transform(scale=1 / 255.)
+        m.set_option('sk2', 0)                 # compare the two families themselves (round 5's split-K path would take the small layers)
         m.set_option('dbg', dbg)
         a = m.embed(x)
         a2 = m.embed(x)
@@ -462,10 +472,12 @@ def test_streamk_fallback_branch(cuda, monkeypatch):
     scheduling-dependent, so force it (DIF_SK_SPIN_LIMIT=-1) and check parity again
     (cdna_hip_programming.md rule 26: a rare branch needs its own test)."""
     monkeypatch.setenv('DIF_SK_SPIN_LIMIT', '-1')
+    monkeypatch.setenv('DIF_OPTIONS', 'sk2=0')       # batch 3 would otherwise run on the split-K path: no stream-K at all
     model, p = build('iresnet50', 'v2', 512, max_batch=3)
     x = scaled(crops_u8(3, seed=77))
     got = model.predict_on_batch(x)
     monkeypatch.delenv('DIF_SK_SPIN_LIMIT')
+    monkeypatch.delenv('DIF_OPTIONS')
     want = nets.embed(x, p, 'iresnet50', 512, 'v2')
     assert cosine_gap(got, want).max() < TOL
     ref_model, _ = build('iresnet50', 'v2', 512, max_batch=3)
@@ -554,3 +566,36 @@ def test_mfma_clock_probe(cuda):
     assert 1.0 < conv_ghz <= 2.45, conv_ghz
     assert torch.equal(model.embed(x), ref)                    # the measuring forward leaves no state behind
     model.close()
+
+
+@pytest.mark.parametrize('arch,head,emd,shape,n', [('resnet', 'v2', 512, (112, 112, 3), 1), ('resnet', 'v2', 512, (112, 112, 3), 12),
+                                                   ('resnet', 'v1', 128, (112, 112, 3), 3), ('iresnet50', 'v2', 512, (112, 112, 3), 1),
+                                                   ('iresnet100', 'v2', 512, (112, 112, 3), 8), ('iresnet50', 'v2', 512, (112, 112, 3), 33),
+                                                   ('mobilenet', 'v2', 512, (112, 112, 3), 5), ('vgg16', 'v2', 512, (112, 112, 3), 2),
+                                                   ('yolov3', 'v3', 1, (416, 416, 3), 1)])
+def test_splitk_path_equals_streamk_path(cuda, arch, head, emd, shape, n):
+    """Round 5: at small batches the few-tile / long-K layers run as conv_sk_kernel (split-K partials, no hand-over inside
+    the launch) + conv_sk_reduce_kernel (fixed-order sum + the layer's epilogue from the MFMA layout); option 'sk2' = 0
+    keeps them on round 4's kernels.  Same products, another (fixed) summation order: embeddings agree to float32 rounding,
+    run to run bit-identical.  Networks cover pre-activation (ResNet50V2), PReLU + two outputs + sub-sampled first outputs +
+    strided shortcuts (IResNet), ReLU6 / depthwise neighbours (MobileNetV2), the flattening fc, concat views and 18-channel
+    heads (YOLOv3-face)."""
+    import torch
+    from deep_insight_face.networks.triplet import DifEmbedder
+    rng = np.random.default_rng(n * 7 + len(arch))
+    x = torch.from_numpy(rng.integers(0, 256, (n,) + shape, dtype=np.uint8)).cuda()
+    m = DifEmbedder(arch, head, emd, shape, max_batch=n).init_synthetic(13)
+    m.set_input_transform(scale=1 / 255.)
+    a = m.embed(x)
+    a2 = m.embed(x)
+    kernels = [k for _, k, _, _ in m.profile(x)]
+    assert any(k.startswith('conv_sk_kernel') for k in kernels), kernels
+    m.set_option('sk2', 0)
+    b = m.embed(x)
+    assert not any(k.startswith('conv_sk_kernel') for _, k, _, _ in m.profile(x))
+    a, a2, b = [t if isinstance(t, list) else [t] for t in (a, a2, b)]
+    for ta, ta2, tb in zip(a, a2, b):
+        assert torch.equal(ta, ta2)                                       # deterministic
+        scale = max(float(tb.abs().max()), 1.0)
+        assert float((ta - tb).abs().max()) <= (2e-5 if arch == 'yolov3' else 4e-6) * scale, arch
+    m.close()

@@ -585,3 +585,106 @@ def test_match_bd_kernel_equals_tile_kernel(cuda, G, B):
         oi, _, _ = od.match(probes[rows].cpu().numpy(), gal_t.cpu().numpy(), metric)
         assert np.array_equal(i1[rows].cpu().numpy(), oi)
     g.close()
+
+
+@pytest.mark.parametrize('flt', [2, 1, 0])
+def test_gallery_update_equals_set(cuda, golden_dir, flt):
+    """dif_gallery_update (round 5: enrolling k identities costs O(k)): overwriting rows in place,
+    appending within and beyond the capacity, replacing a degenerate (zero / NaN / huge) row by an ordinary one and the
+    other way round -- after every step the answers (index, distance bits, key bits; both metrics) are those of a fresh
+    dif_gallery_set with the same rows, and on the degenerate fixture those of the reference."""
+    from deep_insight_face import oneshot
+    rng = np.random.default_rng(500 + flt)
+    base = gi.gallery(6000, seed=93)
+    probes, pick = gi.probes_from(base, 96, seed=94)
+
+    def same_as_fresh(g, rows, p=probes):
+        fresh = oneshot.Gallery(emd_size=512)
+        fresh.set_option('filter', flt)
+        fresh.set(rows)
+        for metric in (0, 1):
+            a = g.match(p, metric, return_key=True)
+            b = fresh.match(p, metric, return_key=True)
+            assert np.array_equal(a[0], b[0]), metric
+            assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), metric
+            assert np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32)), metric
+        fresh.close()
+
+    g = oneshot.Gallery(emd_size=512)
+    g.set_option('filter', flt)
+    g.set(base[:5000])
+    assert g.capacity == 5000 and len(g) == 5000
+    cur = base[:5000].copy()
+    # overwrite in place: 8 rows become noisy copies of probes (the bench's "plant" step)
+    new = probes[:8] + np.float32(0.001) * rng.standard_normal((8, 512)).astype(np.float32)
+    g.update(new, 1234)
+    cur[1234:1242] = new
+    same_as_fresh(g, cur)
+    i, _ = g.match(probes[:8], 1)
+    assert np.array_equal(i, np.arange(1234, 1242))
+    # append beyond the capacity (grows), then inside it
+    g.update(base[5000:5600])
+    cur = np.concatenate([cur, base[5000:5600]])
+    assert len(g) == 5600 and g.capacity >= 5600
+    same_as_fresh(g, cur)
+    g.reserve(9000)
+    assert g.capacity == 9000 and len(g) == 5600
+    g.update(base[5600:6000], 5600)
+    cur = np.concatenate([cur, base[5600:6000]])
+    same_as_fresh(g, cur)
+    # degenerate rows come ...
+    bad = np.zeros((4, 512), np.float32)
+    bad[1, 3] = np.nan
+    bad[2] = base[77] * np.float32(1e19)
+    bad[3] = base[78] * np.float32(1e-25)
+    g.update(bad, 40)
+    cur[40:44] = bad
+    same_as_fresh(g, cur)
+    # ... and go (the special lists must forget them: a stale first-NaN row would hide a later one)
+    g.update(base[40:42], 40)
+    cur[40:42] = base[40:42]
+    same_as_fresh(g, cur)
+    g.update(base[42:44], 42)
+    cur[42:44] = base[42:44]
+    same_as_fresh(g, cur)
+    with pytest.raises(ValueError):
+        g.update(base[:3], len(g) + 1)              # a gap
+    with pytest.raises(ValueError):
+        g.update(base[:3, :100])
+    g.close()
+    # the reference's own answers: every degenerate fixture rebuilt row group by row group through update
+    gold = np.load(os.path.join(golden_dir, 'match_degenerate.npz'))
+    for name, p, gl in gi.match_degenerate_cases():
+        h = oneshot.Gallery(emd_size=gl.shape[1])
+        h.set_option('filter', flt)
+        h.set(gl[::-1].copy())                      # other rows first (special rows at other places)
+        step = max(1, gl.shape[0] // 3 + 1)
+        for lo in range(0, gl.shape[0], step):
+            h.update(gl[lo:lo + step], lo)
+        for metric in (0, 1):
+            idx, dist = h.match(p, metric)
+            assert np.array_equal(idx, gold['%s_idx%d' % (name, metric)]), (name, metric)
+            assert np.array_equal(np.isnan(dist), np.isnan(gold['%s_dmin%d' % (name, metric)])), (name, metric)
+        h.close()
+
+
+def test_probe_workspace_survives_a_non_monotone_batch_sequence(cuda):
+    """the probes' fragment-order copy was grown under the per-probe capacity but sized B + 32, so a
+    call that only grew the partial-result workspace could reallocate it SMALLER than an earlier, larger batch needed and
+    the next such batch wrote past its end (two-term filter: 4 B per value).  Batches 513 -> 482 -> 513 on a gallery
+    large enough for the part count to differ; answers equal the one-term filter's and the planted rows."""
+    from deep_insight_face import oneshot
+    G = 1_000_000
+    gen = torch.Generator(device='cuda').manual_seed(11)
+    gal_t = torch.nn.functional.normalize(torch.randn((G, 512), device='cuda', generator=gen), dim=1)
+    pick = torch.randperm(G, device='cuda', generator=gen)[:513]
+    probes = torch.nn.functional.normalize(gal_t[pick] + 0.02 * torch.randn((513, 512), device='cuda', generator=gen), dim=1)
+    g = oneshot.Gallery(gal_t)
+    g.set_option('filter', 1)
+    guard = torch.full((1 << 20,), 7.0, device='cuda')          # a neighbour for a stray write to land in
+    for B in (513, 482, 513, 100, 513):
+        i, _ = g.match(probes[:B], 1)
+        assert torch.equal(i, pick[:B]), B
+    torch.cuda.synchronize()
+    assert bool((guard == 7.0).all())
+    g.close()

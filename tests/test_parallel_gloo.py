@@ -121,3 +121,52 @@ def test_force_collectives_world_of_one(tmp_path):
     z = np.load(os.path.join(str(tmp_path), 'f.npz'))
     assert int(z['calls0']) == 0 and int(z['calls1']) == 2
     assert np.array_equal(z['idx0'], z['idx1']) and np.array_equal(z['d0'], z['d1'])
+
+
+def _ragged_worker(rank, world, port, mode, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from deep_insight_face.parallel import ShardedGallery, shard_bounds
+        G = 301
+        gal = gi.gallery(G, seed=3)
+        probes, _ = gi.probes_from(gal, 16, seed=4)
+        lo, hi = shard_bounds(G, world, rank)
+        sg = ShardedGallery(gal[lo:hi], lo, match_fn=_oracle_match, merge_fn=_cpu_merge, check_batch=mode)
+        log = []
+        if mode == 'always':
+            # a full step first (shape cached on both ranks), THEN the ragged last batch: rank 0 still brings 5 probes
+            idx, _ = sg.match(torch.from_numpy(probes[rank * 5:(rank + 1) * 5]), 1)
+            log.append('ok%d' % len(idx))
+        b = 5 if rank == 0 else 4
+        try:
+            sg.match(torch.from_numpy(probes[:b]), 1)
+            log.append('no error')
+        except ValueError as e:
+            log.append('ValueError: %s' % e)
+        # the group is still usable afterwards (both ranks left the step at the same collective)
+        idx, _ = sg.match(torch.from_numpy(probes[rank * 3:(rank + 1) * 3]), 1)
+        log.append('ok%d' % len(idx))
+        with open(os.path.join(out_dir, 'r%d.txt' % rank), 'w') as fh:
+            fh.write('\n'.join(log))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('mode', ['always', 'first'])
+def test_ragged_batch_across_ranks_raises(tmp_path, mode):
+    """ShardedGallery.match sized its gather buffers from THIS rank's b; ranks with b = 5 and 4
+    (a ragged last batch) gave a size-mismatched all_gather_into_tensor -- hang or garbage.  Now every rank raises
+    ValueError naming the sizes, before any buffer is touched, and the next well-formed step works."""
+    mp.spawn(_ragged_worker, args=(2, _free_port(), mode, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        log = open(os.path.join(str(tmp_path), 'r%d.txt' % r)).read().split('\n')
+        if mode == 'always':
+            assert log[0] == 'ok10'
+            log = log[1:]
+        assert log[0].startswith('ValueError') and '[5, 4]' in log[0], log
+        assert log[1] == 'ok6'
+    from deep_insight_face.parallel import ShardedGallery
+    with pytest.raises(ValueError, match='check_batch'):
+        ShardedGallery(np.zeros((4, 8), np.float32), 0, match_fn=_oracle_match, check_batch='sometimes')
