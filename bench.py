@@ -337,6 +337,7 @@ def main():
     ap.add_argument('--gallery', type=int, default=0, help='total gallery rows override')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-throughput-mode', action='store_true', help='skip the extra split-bf16 forward timing')
+    ap.add_argument('--no-latency', action='store_true', help='skip the small-batch (1 / 8 / 32) forward latency block')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='gloo = rehearsal of the N>1 path on a box with fewer GPUs than ranks (collectives staged '
                          'through the host, ranks share devices); never used for reported numbers')
@@ -415,7 +416,9 @@ def main():
     model.embed, model.embed_into = _counted_embed, _counted_embed_into
     lo, hi = shard_bounds(gallery_rows, world, rank)
     shard_rows = synthetic_gallery(lo, hi, 512, 7, dev)       # kept: the self-check after the timed region plants rows
-    shard = ShardedGallery(shard_rows, lo, force_collectives=args.force_collectives)
+    # check_batch='first': the ranks' probe counts are compared when a step shape is first met (the warm-up), not inside
+    # the timed loop -- the per-step check reads a value back to the host (parallel.py)
+    shard = ShardedGallery(shard_rows, lo, force_collectives=args.force_collectives, check_batch='first')
     emb_buf = torch.empty((batch, 512), dtype=torch.float32, device=dev)   # the serving loop allocates nothing per step
     arc = None
     if args.workload == 'r100_arc':
@@ -473,6 +476,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    shard.phase_events = []                                   # five HIP events per timed step around the collectives (parallel.py)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -484,6 +488,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    step_events, shard.phase_events = shard.phase_events, None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -500,8 +505,7 @@ def main():
     probe_ids = probe_ids[:len(plant_rows)]
     for pid, row in zip(probe_ids, plant_rows):
         if lo <= row < hi:
-            shard_rows[row - lo] = emb_all[pid]
-    shard.gallery.set(shard_rows, lo)
+            shard.gallery.update(emb_all[pid:pid + 1], row - lo)   # O(1) per enrolment (dif_gallery_update), not a whole-gallery pass
     idx_v, d_v = step()
     torch.cuda.synchronize()
     got = [int(idx_v[pid]) for pid in probe_ids]
@@ -513,6 +517,50 @@ def main():
 
     embed_ms = float(np.mean([ev[i][0].elapsed_time(ev[i][1]) for i in range(args.steps)]))
     match_ms = float(np.mean([ev[i][1].elapsed_time(ev[i][2]) for i in range(args.steps)]))
+    # the match phase taken apart (rank 0's view): [start, embeddings gathered, local match done, records gathered, merged]
+    sub = {}
+    if step_events:
+        for name, a_, b_ in (('allgather_embed', 0, 1), ('match_local', 1, 2), ('allgather_packed', 2, 3), ('merge', 3, 4)):
+            sub[name] = float(np.mean([e[a_].elapsed_time(e[b_]) for e in step_events]))
+    # every rank's embed / match phase, so that a non-linear point of the scaling curve can be placed (slowest rank, or the exchange)
+    per_rank = None
+    if world > 1:
+        mine = torch.tensor([embed_ms, match_ms] + [sub.get(k, 0.0) for k in ('allgather_embed', 'match_local', 'allgather_packed', 'merge')],
+                            dtype=torch.float64, device=dev)
+        allr = torch.empty((world * mine.numel(),), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allr, mine)
+        allr = allr.view(world, -1).cpu().numpy()
+        per_rank = {k: {'min': float(allr[:, i].min()), 'max': float(allr[:, i].max()), 'argmax_rank': int(allr[:, i].argmax())}
+                    for i, k in enumerate(('embed', 'match', 'allgather_embed', 'match_local', 'allgather_packed', 'merge'))}
+
+    # the reference's own call shapes (predictions.py:152-156 embeds ONE image per call; scripts/insight_face.py:112 evaluates at
+    # batch 12): forward latency at small batches, same model and weights, HIP events over back-to-back forwards
+    latency = None
+    if pipe is None and compute == 'f32' and not args.no_latency:
+        latency = {}
+        for lb in (1, 8, 32):
+            if lb > batch:
+                continue
+            xs = crops[:lb]
+            ob = emb_buf[:lb]
+            for _ in range(5):
+                model.embed_into(xs, ob)
+            reps = 30
+            le = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            torch.cuda.synchronize()
+            tw = time.perf_counter()
+            le[0].record()
+            for _ in range(reps):
+                model.embed_into(xs, ob)
+            le[1].record()
+            torch.cuda.synchronize()
+            wall = (time.perf_counter() - tw) / reps * 1e3
+            ms = le[0].elapsed_time(le[1]) / reps
+            tf = model.flops_per_image * lb / (ms * 1e-3) / 1e12
+            latency['b%d' % lb] = {'ms': ms, 'wall_ms': wall, 'faces_per_s': lb / (wall * 1e-3), 'tflops': tf,
+                                   'frac': tf / PEAK_F32_MFMA_TFLOPS}
+        latency['note'] = ('forward only, f32; ms = HIP events over 30 back-to-back forwards on the launch stream, wall_ms = host clock '
+                           'around the same loop; frac = algorithmic TFLOP/s over the f32-MFMA peak')
 
     # north_star states its MFMA target "on the ResNet-100 embedding forward at batch 256": time that forward
     # too (same model, same lanes policy, HIP events on the launch stream), outside the step loop
@@ -587,7 +635,9 @@ def main():
                        'gallery_rows_per_gpu': hi - lo, 'emd': 512, 'metric': 'cosine',
                        'parallelism': 'dp%d + gallery row-shard' % world, 'backend': args.backend if grouped else None},
             'forwards_in_process': {str(k): v for k, v in sorted(forwards.items())},
-            'phases_ms': ({'embed': embed_ms, 'match': match_ms} if pipe is None else
+            'latency': latency,
+            'phases_per_rank_ms': per_rank,
+            'phases_ms': (dict({'embed': embed_ms, 'match': match_ms}, **sub) if pipe is None else
                           {'detect+crop': float(np.mean([ev[i][0].elapsed_time(det_ms[i]) for i in range(args.steps)])),
                            'detect+crop+embed': embed_ms, 'match': match_ms}),
             'roofline': {

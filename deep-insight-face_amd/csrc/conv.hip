@@ -2383,18 +2383,34 @@ static int launch_conv_pw(const ConvArgs& a, hipStream_t st) {
 // SK2_MIN_KS K-steps; 0 = the path does not apply.  A pure function of the layer's shape and the batch (deterministic sums).
 constexpr int SK2_MIN_KS = 4;
 static int sk2_plan(const ConvArgs& a) {
-  if ((a.off & CONV_OFF_SK2) || a.trace) return 0;
+  if ((a.off & CONV_OFF_SK2) || (a.trace && !(a.dbg & 256))) return 0;   // (the clock measurement keeps round 4's kernels; the block trace, dbg 256, sees this path)
+  const bool pw1 = a.KH == 1 && a.KW == 1 && a.pad_t == 0 && a.pad_l == 0 && a.Cin % BK == 0;
+  if (!pw1 && !(a.k_order == 1 && a.Cin % BK == 0)) return 0;          // the loaders' two K layouts (conv_splitk.hpp)
   const int64_t tiles = ((a.M + 63) / 64) * (int64_t)((a.Cout + 63) / 64);
   const int KS = a.Kpad / BK;
-  const int64_t target = 2 * (int64_t)num_cus();
-  if (tiles >= target || KS < 2 * SK2_MIN_KS) return 0;
-  int64_t S = (target + tiles - 1) / tiles;
-  if (S > KS / SK2_MIN_KS) S = KS / SK2_MIN_KS;
+  const int64_t cus = num_cus();
+  if (tiles >= 2 * cus || KS < 2 * SK2_MIN_KS) return 0;
   const int64_t cap = (int64_t)a.sk_max_blocks * (int64_t)conv_slab_floats() / 4096;   // slabs the workspace holds
-  if (tiles * S > cap) S = cap / tiles;
+  // S minimising  rounds(S) x share(S) + 0.1 S  in K-steps: rounds = blocks per CU (co-resident blocks share the CU's matrix
+  // pipes, so their K-steps add up), share = K-steps per block, and every split costs the reduce launch one more slab to read
+  int64_t S = 0;
+  double best = 1e30;
+  for (int64_t s = 2; s <= KS / SK2_MIN_KS && tiles * s <= 4 * cus && tiles * s <= cap; ++s) {
+    const double cost = (double)((tiles * s + cus - 1) / cus) * (double)((KS + s - 1) / s) + 0.1 * (double)s;
+    if (cost < best) {
+      best = cost;
+      S = s;
+    }
+  }
+  // (against no split at all: rounds(1) x KS)
+  if (S && (double)((tiles + cus - 1) / cus) * (double)KS <= best) S = 0;
   return S >= 2 ? (int)S : 0;
 }
 
+// (Requesting so much LDS per block that no CU can hold more than the plan's rounds = ceil(blocks / CUs) of them -- to make
+// the dispatcher deal a ~2-blocks-per-CU grid evenly: block lives of one 500-block launch range 12 .. 25 us -- was measured:
+// the longest life drops (25 -> 20 us) but blocks then WAIT for a slot (span 25 -> 29 us), and batch 1 loses 10 %:
+// profiles/r05_ablation.txt item 2.)
 template <bool PRE, int AM>
 static int launch_conv_sk(const ConvArgs& a, int S, hipStream_t st) {
   using T = Tile<1, 1>;
@@ -2410,6 +2426,7 @@ static int launch_conv_sk(const ConvArgs& a, int S, hipStream_t st) {
   if (a.k_order == 1 && a.Cin % BK != 0) return set_error("conv: channel-block-major K order needs Cin %% 32 == 0");
   const int pairs = tiles_n * S;
   const unsigned grid = (unsigned)(((pairs + 7) / 8) * 8 * tiles_m);
+  if ((int64_t)grid > a.sk_max_blocks) b.trace = nullptr;     // (the trace buffer holds that many records per launch)
   hipLaunchKernelGGL(kern, dim3(grid), dim3(T::NT), T::LDS_BYTES, st, b, S, tiles_m, tiles_n);
   DIF_HIP(hipGetLastError());
   hipLaunchKernelGGL(conv_sk_reduce_kernel, dim3((unsigned)(tiles_m * tiles_n * 16)), dim3(64), 0, st, b, S, tiles_n);
@@ -2424,10 +2441,42 @@ static int launch_conv_sk(const ConvArgs& a, int S, hipStream_t st) {
   return 0;
 }
 
+template <int AMP>
+static int launch_conv_skp(const ConvArgs& a, int S, hipStream_t st) {
+  using T = Tile<1, 1>;
+  void (*kern)(const ConvArgs, int, int, int) = conv_skp_kernel<T, AMP>;
+  constexpr int lds_bytes = (AMP == 5 ? PATCH_EMAX_L : PATCH_EMAX_S) * 128;
+  if (allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds_bytes)) return -1;
+  const int tiles_m = (a.M + 63) / 64, tiles_n = (a.Cout + 63) / 64;
+  ConvArgs b = a;
+  b.fd_howo = make_fastdiv(a.Ho * a.Wo);
+  b.fd_wo = make_fastdiv(a.Wo);
+  b.fd_wp = make_fastdiv(a.W + 2);
+  b.fd_rpi = make_fastdiv(a.H + 1);
+  const int pairs = tiles_n * S;
+  const unsigned grid = (unsigned)(((pairs + 7) / 8) * 8 * tiles_m);
+  if ((int64_t)grid > a.sk_max_blocks) b.trace = nullptr;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(T::NT), lds_bytes, st, b, S, tiles_m, tiles_n);
+  DIF_HIP(hipGetLastError());
+  hipLaunchKernelGGL(conv_sk_reduce_kernel, dim3((unsigned)(tiles_m * tiles_n * 16)), dim3(64), 0, st, b, S, tiles_n);
+  DIF_HIP(hipGetLastError());
+  {
+    static std::mutex mu;
+    static std::set<std::string> names;
+    std::lock_guard<std::mutex> lock(mu);
+    g_last_kernel = names.insert(std::string("conv_skp_kernel<64x64,") + am_form(AMP + 10) + ",S=" + std::to_string(S) + ">+reduce").first->c_str();
+  }
+  return 0;
+}
+
 template <class T>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
   if constexpr (T::BM == 64 && T::BN == 64) {
     if (const int S = sk2_plan(a)) {
+      // 3x3 / stride 1 layers whose linear halo patch fits: the B-direct patch mainloop (dbg bit 16384 keeps the gather: A/B)
+      const int emax = (!(a.off & CONV_OFF_BD) && a.w_frag && !(a.dbg & 16384)) ? patch_applies(a) : 0;
+      if (emax == PATCH_EMAX_S) return launch_conv_skp<3>(a, S, st);
+      if (emax == PATCH_EMAX_L) return launch_conv_skp<5>(a, S, st);
       const bool pw1 = a.KH == 1 && a.KW == 1 && a.pad_t == 0 && a.pad_l == 0 && a.Cin % BK == 0;
       if (pw1) return a.pre_scale ? launch_conv_sk<true, 1>(a, S, st) : launch_conv_sk<false, 1>(a, S, st);
       return a.pre_scale ? launch_conv_sk<true, 0>(a, S, st) : launch_conv_sk<false, 0>(a, S, st);

@@ -206,8 +206,21 @@ int dif_gallery_update(dif_gallery* h, const float* rows_dev, int64_t n, int64_t
 int64_t dif_gallery_size(const dif_gallery* h) { return h ? h->g.n : 0; }
 int64_t dif_gallery_capacity(const dif_gallery* h) { return h ? h->g.cap : 0; }
 
+static const char* const kGalleryOptions[] = {"filter", "clamp_nan", "bd", "bd_fill", nullptr};
+
+const char* dif_gallery_option_name(int i) {
+  int n = 0;
+  while (kGalleryOptions[n]) ++n;
+  return i >= 0 && i < n ? kGalleryOptions[i] : nullptr;
+}
+
 int dif_gallery_set_option(dif_gallery* h, const char* key, int value) {
   if (!h || !key) return set_error("dif_gallery_set_option: null argument");
+  {
+    bool known = false;
+    for (const char* const* t = kGalleryOptions; *t; ++t) known |= std::string(*t) == key;
+    if (!known) return set_error("dif_gallery_set_option: unknown key '%s'", key);
+  }
   if (std::string(key) == "clamp_nan") {
     h->g.clamp_nan = value != 0;
     return 0;

@@ -876,7 +876,19 @@ static void fold(const Net* net, const BNRef& bn, int bias, int C, std::vector<f
 
 // dif_net_set_option (include/dif.h documents the keys a caller may rely on; the rest are development switches that
 // pick between kernel families the parity tests compare)
+// every key set_option accepts (dif_net_option_name: include/dif.h documents each one, and a test holds it to that)
+const char* const* Net::option_names() {
+  static const char* const names[] = {"pipe", "bdp", "stem", "patch", "patch2d", "bd", "t2", "tn", "sk2", "pw", "bf16x3",
+                                      "bf_terms", "ysub", "lane_split", "lane_prio", "dbg", nullptr};
+  return names;
+}
+
 int Net::set_option(const char* key, int value) {
+  {
+    bool known = false;
+    for (const char* const* t = option_names(); *t; ++t) known |= !strcmp(*t, key);
+    if (!known) return set_error("dif_net_set_option: unknown option '%s'", key);
+  }
   auto flag = [&](unsigned bit) {
     conv_off = value ? (conv_off & ~bit) : (conv_off | bit);
     return 0;
@@ -896,6 +908,10 @@ int Net::set_option(const char* key, int value) {
   if (!strcmp(key, "tn")) return flag(CONV_OFF_TN);
   if (!strcmp(key, "sk2")) return flag(CONV_OFF_SK2);
   if (!strcmp(key, "pw")) {                                 // conv_pw_kernel is OFF by default: the bit means "on" for this family
+    // its fragment-order weight copy is built at finalize only when the option is on by then (it doubled the
+    // pointwise weights of every net for a path that is off by default): on -> off any time, off -> on before finalize
+    if (value && !pre && !pw_frag_built)
+      return set_error("dif_net_set_option: 'pw' = 1 must be chosen before dif_net_finalize (it needs its own weight layout)");
     conv_off = value ? (conv_off | CONV_OFF_PW) : (conv_off & ~CONV_OFF_PW);
     return 0;
   }
@@ -918,7 +934,7 @@ int Net::set_option(const char* key, int value) {
     else opt_lane_split = value < 0 ? -1 : (value != 0);
     return 0;
   }
-  return set_error("dif_net_set_option: unknown option '%s'", key);
+  return set_error("dif_net_set_option: option '%s' is listed but not handled", key);   // option_names() and this chain out of step
 }
 
 int Net::finalize(int mb) {
@@ -1012,8 +1028,9 @@ int Net::finalize(int mb) {
       op.d_w_frag = nullptr;
       op.w_frag_bytes = 0;
       // ... and every pointwise layer conv_pw_kernel can take (1x1 / stride 1, whole 64-channel K and column blocks)
-      const bool pw_layer = op.KH == 1 && op.KW == 1 && op.stride == 1 && op.pad_t == 0 && op.pad_l == 0 && op.Cin % 64 == 0 &&
-                            op.Cin_true == op.Cin && op.Cout % 64 == 0 && !op.chw_flatten;
+      const bool pw_layer = (conv_off & CONV_OFF_PW) && op.KH == 1 && op.KW == 1 && op.stride == 1 && op.pad_t == 0 && op.pad_l == 0 &&
+                            op.Cin % 64 == 0 && op.Cin_true == op.Cin && op.Cout % 64 == 0 && !op.chw_flatten;
+      if (conv_off & CONV_OFF_PW) pw_frag_built = true;
       if (pw_layer || (!op.d_w3f && op.k_order == 1 && op.KH == 3 && op.KW == 3 && op.stride == 1 && op.pad_t == 1 && op.pad_l == 1 &&
           !op.pre_bn.valid())) {
         const int KS = op.Kpad / BK, NT32 = (op.Cout + 31) / 32;

@@ -102,6 +102,13 @@ int dif_net_set_option(dif_net* h, const char* key, int value) {
   return h->net.set_option(key, value);
 }
 
+const char* dif_net_option_name(int i) {
+  const char* const* t = Net::option_names();
+  int n = 0;
+  while (t[n]) ++n;
+  return i >= 0 && i < n ? t[i] : nullptr;
+}
+
 int dif_net_output_dim(const dif_net* h, int64_t shape[3]) {
   if (!h || !shape) return set_error("dif_net_output_dim: null argument");
   const TensorDesc& t = h->net.tensors[h->net.output_tensor];
@@ -147,11 +154,12 @@ int dif_net_op_traffic(const dif_net* h, int i, double* act_bytes_per_image, dou
   auto elems = [&](int t) -> double { return t >= 0 ? (double)net.tensors[t].elems() : 0.0; };
   double rd = elems(op.x), wr = elems(op.y) + elems(op.y2), par = 0.0;
   if (op.kind == OP_CONV) {
-    const TensorDesc& yd = net.tensors[op.y >= 0 ? op.y : op.y2];
+    // (a sub-sampled first output is stored at a quarter of the size already -- Net::finalize shrank tensors[op.y] --, so the
+    // layer's geometry is read from the other output, as Net::run_op does, and elems(op.y) needs no correction: ADVICE r04)
+    const TensorDesc& yd = net.tensors[op.y >= 0 && !op.y_sub ? op.y : op.y2];
     // a strided 1x1 layer uses one input pixel per output pixel; every other layer its whole input
     if (op.KH == 1 && op.KW == 1 && op.stride > 1 && op.x >= 0)
       rd = (double)yd.H * yd.W * net.tensors[op.x].C;
-    if (op.y_sub && op.y >= 0) wr -= elems(op.y) * 0.75;          // first output kept at even pixels only
     if (op.res >= 0) rd += (double)yd.H * yd.W * yd.C;
     par = (double)op.KH * op.KW * op.Cin_true * op.Cout + 2.0 * op.Cout;
   } else if (op.kind == OP_GDCTAIL || op.kind == OP_DWFULL || op.kind == OP_DWCONV) {

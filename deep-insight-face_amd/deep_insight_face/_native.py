@@ -62,6 +62,8 @@ SIGNATURES = {
     'dif_net_set_input_transform': (c_int, [c_void_p, c_float, P(c_float), c_int]),
     'dif_net_finalize': (c_int, [c_void_p, c_int]),
     'dif_net_set_option': (c_int, [c_void_p, c_char_p, c_int]),
+    'dif_net_option_name': (c_char_p, [c_int]),
+    'dif_gallery_option_name': (c_char_p, [c_int]),
     'dif_net_output_dim': (c_int, [c_void_p, P(c_int64)]),
     'dif_net_output_count': (c_int, [c_void_p]),
     'dif_net_output_info': (c_int, [c_void_p, c_int, P(c_int64)]),

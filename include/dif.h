@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DIF_VERSION 100
+#define DIF_VERSION 110 /* 1.1: + dif_gallery_update / _reserve / _capacity, dif_*_option_name, option "sk2" */
 
 /* distance metrics: evaluation/utility.py:52-66 */
 #define DIF_METRIC_SQL2 0   /* sum((a-b)^2, axis=1)                     utility.py:53-56 */
@@ -139,7 +139,11 @@ int64_t dif_gallery_capacity(const dif_gallery* g);
  * (dif_gallery_get_stat "split_copy" / "filter_terms" tell).
  * "clamp_nan": 0 (default) dif_match reports NaN where the reference's distance is NaN; 1 reports the
  * distance of the similarity clamped to [-1, 1] instead (0 for a similarity rounded above 1, 1 below -1).  The
- * arg-min is the reference's either way. */
+ * arg-min is the reference's either way.
+ * "bd": 1 (default) the two-term filter ("filter" = 1) runs on match_bd_kernel from 65 probes up; 0 keeps it on
+ * match_tile_kernel for every batch (tests, A/B).  Same answers.
+ * "bd_fill": 1 (default) .. 16: blocks of match_bd_kernel per resident slot (development; no effect measured).
+ * Every key the library accepts is listed here (dif_gallery_option_name; tests/test_cabi_symbols.py). */
 int dif_gallery_set_option(dif_gallery* g, const char* key, int value);
 /* read-outs (no reference counterpart; for capacity planning and tests).  "split_copy": 1 when the filter's bf16 copy
  * of the current rows exists; "filter_terms": bf16 terms per operand the next dif_match's filter runs on (1 or 2; 0 = the f32 rows);
@@ -189,18 +193,50 @@ int dif_net_get_param(const dif_net* net, const char* name, float* data_host, in
 int dif_net_set_input_transform(dif_net* net, float scale, const float bias[3], int flags);
 /* pack weights for the kernels, upload, and size the activation workspace */
 int dif_net_finalize(dif_net* net, int max_batch);
-/* execution options (no reference counterpart: Keras picks its kernels by itself).  Keys:
- *   "pipe"  1 (default) lets short-K convolutions take the software-pipelined kernel, 0 keeps every
- *           convolution on the plain implicit-GEMM kernel (the two are compared by the parity tests)
- *   "bdp"   1 (default) lets 3x3 / stride 1 layers with several tiles per resident block take the kernel that retires a
- *           tile's epilogue inside the next tile's K-steps (conv.hip: conv_bdp_kernel), 0 never, 2 wherever its
- *           restrictions allow (the parity tests compare 0 and 2)
- *   "stem"  1 (default) runs 3-channel first layers on their own kernels (stem.hip, elementwise.hip), 0 on the general
- *           implicit-GEMM kernel (compared by the parity tests)
- *   "bf16x3" 0 (default): float32 MFMA, a bit-exact f32 fma chain -- the reference's arithmetic;
- *           1 (before dif_net_finalize): throughput mode -- every f32 operand split into three bf16 terms, six
- *           bf16 MFMA products accumulated in f32 (f32-level accuracy, same 1e-5 cosine gate, not bit-identical) */
+/* execution options (no reference counterpart: Keras picks its kernels by itself).  EVERY key the library accepts is
+ * listed here with its default (tests/test_cabi_symbols.py compares this list with dif_net_option_name); an unknown key
+ * fails.  Unless a key says "before dif_net_finalize" it may be changed between forwards.  Most keys choose between
+ * kernel families that compute the same products (the parity tests run both sides); none changes what is computed.
+ *   "pipe"       1 (default): short-K convolutions may take the software-pipelined kernel (conv_pipe_kernel);
+ *                0: every convolution stays on the plain implicit-GEMM kernel
+ *   "bdp"        1 (default): 3x3 / stride 1 layers with several tiles per resident block may take the kernel that retires
+ *                a tile's epilogue inside the next tile's K-steps (conv_bdp_kernel); 0: never; 2: wherever its
+ *                restrictions allow (tests)
+ *   "stem"       1 (default): 3-channel first layers run on their own kernels (stem.hip, elementwise.hip); 0: on the
+ *                general implicit-GEMM kernel
+ *   "patch"      1 (default): 3x3 / stride 1 / pad 1 layers keep the tile's input pixels + halo in LDS per 32-channel
+ *                slice (a tap is an address offset); 0: the per-K-step gather
+ *   "patch2d"    1 (default): the 8x8-tile form of that path on maps whose sides are multiples of 8; 0: off
+ *   "bd"         1 (default): the patch kernels fetch the weights in MFMA-fragment order straight from L2 into registers
+ *                (B-direct mainloop); 0: weights staged through LDS
+ *   "t2"         1 (default): short-K 3x3 layers on 8-aligned maps run on conv_t2_kernel (128 pixels x 64 channels per
+ *                block, two 8x8 sub-tiles); 0: the 64 x 64 kernels
+ *   "tn"         1 (default): linear-patch 3x3 layers with whole 128-channel column blocks run on conv_tn_kernel
+ *                (64 pixels x 128 channels per block, one whole tile per block); 0: conv_bdp_kernel / conv_igemm_kernel
+ *   "sk2"        1 (default): layers with few tiles and a long K loop -- the reference's own call shapes, ONE image
+ *                (predictions.py:152-156) or a batch of 12 (scripts/insight_face.py:112) -- run as split-K partials +
+ *                a reduce / epilogue launch (conv_splitk.hpp); 0: round 4's persistent stream-K grid
+ *   "pw"         0 (default); 1 (before dif_net_finalize: it lays the pointwise weights out once more; back to 0 any time):
+ *                1x1 / stride 1 layers run on the barrier-free pointwise kernel (conv_pw_kernel: bit-identical, slower
+ *                inside the two-lane executor)
+ *   "bf16x3"     0 (default): float32 MFMA, a bit-exact f32 fma chain -- the reference's arithmetic;
+ *                1 (before dif_net_finalize): throughput mode -- every f32 operand split into bf16 terms, bf16 MFMA
+ *                products accumulated in f32 (f32-level accuracy, same 1e-5 cosine gate, not bit-identical)
+ *   "bf_terms"   3 (default) or 2: bf16 terms per operand in that mode (six / three MFMA products per multiply-add)
+ *   "ysub"       1 (default; before dif_net_finalize): a first output read only by a 1x1 / stride 2 layer is written at
+ *                even pixels only; 0: written whole
+ *   "lane_split" -1 (default; before dif_net_finalize): the executor's lanes run half-chip persistent grids where the
+ *                work per launch is small; 0: whole-chip grids; 1: half-chip grids always
+ *   "lane_prio"  0 (default; before dif_net_finalize): all lanes of a multi-lane forward run on least-priority streams
+ *                (own hardware queues, whatever else the process created); 1: lane 0 on the caller's stream
+ *   "dbg"        0 (default): development aid, bit mask (256: block traces from dif_net_embed_clock; 1024: every layer on
+ *                the general epilogue; other bits: ablations of the kernel under work)
+ * env DIF_OPTIONS="key=value,..." applies keys to every net of the process at dif_net_finalize (A/B runs of the tools). */
 int dif_net_set_option(dif_net* net, const char* key, int value);
+/* the i-th key dif_net_set_option / dif_gallery_set_option accepts, NULL past the last one (so that the list above can be
+ * checked against the library) */
+const char* dif_net_option_name(int i);
+const char* dif_gallery_option_name(int i);
 int dif_net_output_dim(const dif_net* net, int64_t shape[3]); /* {emd,1,1} or {C,H,W} for v3 */
 /* networks with several outputs (arch "yolov3": the three detection maps, coarse first; emd_size
  * carries the class count): out_dev then holds output 0 for all n images, then output 1, ... */

@@ -33,7 +33,35 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in declared() if not hasattr(lib, n)]
     assert not missing, missing
     lib.dif_version.restype = ctypes.c_int
-    assert lib.dif_version() == 100
+    assert lib.dif_version() == 110
+    assert re.search(r'#define DIF_VERSION 110\b', open(HEADER).read())
+
+
+def _option_block(fn):
+    """The comment in front of `int <fn>(` in the header."""
+    src = open(HEADER).read()
+    end = src.index('int %s(' % fn)
+    start = src.rindex('/*', 0, end)
+    return src[start:end]
+
+
+@pytest.mark.parametrize('setter,lister', [('dif_net_set_option', 'dif_net_option_name'),
+                                           ('dif_gallery_set_option', 'dif_gallery_option_name')])
+def test_header_documents_every_option_the_library_accepts(setter, lister):
+    """the header is the boundary, and it listed 4 of ~17 keys.  The library reads out its key table
+    (dif_*_option_name); every key must be named, in quotes, with a default, in the comment of its setter."""
+    lib = ctypes.CDLL(LIB)
+    fn = getattr(lib, lister)
+    fn.restype = ctypes.c_char_p
+    fn.argtypes = [ctypes.c_int]
+    keys = []
+    while fn(len(keys)) is not None:
+        keys.append(fn(len(keys)).decode())
+        assert len(keys) < 100
+    assert fn(-1) is None and len(keys) >= 4 and len(set(keys)) == len(keys)
+    doc = _option_block(setter)
+    missing = [k for k in keys if not re.search(r'"%s"[^"]{0,400}?default' % re.escape(k), doc, flags=re.S)]
+    assert not missing, 'include/dif.h does not document: %s' % missing
 
 
 def test_binding_table_matches_header():
