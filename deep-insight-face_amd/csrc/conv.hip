@@ -1081,6 +1081,7 @@ struct NoLoader {};   // B operand of the B-direct kernels: fetched by the mainl
 #undef IGEMM_BF_MAINLOOP
 
 #include "conv_splitk.hpp"
+#include "conv_minitile.hpp"
 
 // ------------------------------------------------------------------------------------------
 // Software-pipelined variant for layers with a SHORT K loop and several tiles per resident block
@@ -2441,6 +2442,48 @@ static int launch_conv_sk(const ConvArgs& a, int S, hipStream_t st) {
   return 0;
 }
 
+// ---- the one-image path (conv_minitile.hpp): waves per block, or 0 when the layer is not for it
+static int mt_plan(const ConvArgs& a) {
+  if ((a.off & CONV_OFF_MT) || a.trace || !a.w_f16) return 0;
+  const bool pw1 = a.KH == 1 && a.KW == 1 && a.pad_t == 0 && a.pad_l == 0 && a.Cin % BK == 0;
+  if (!pw1 && !(a.k_order == 1 && a.Cin % BK == 0)) return 0;
+  if ((int64_t)a.N * a.H * a.W * a.Cin * 4 >= 0x7fffffffLL || (int64_t)16 * a.Kpad * 4 >= 0x7fffffffLL) return 0;   // 32-bit offsets
+  const int64_t tiles = ((a.M + 15) / 16) * (int64_t)((a.Cout + 15) / 16);
+  const int64_t traffic = tiles * 32 * (int64_t)a.Kpad * 4;          // L2 -> CU bytes: no operand is reused inside a tile
+  if (tiles > 2 * (int64_t)num_cus() || traffic > (96ll << 20)) return 0;        // (the 784 tiles of a 56 x 56 x 64 layer: split-K is faster)
+  const int nch = a.Kpad / 16;
+  const bool pre = a.pre_scale != nullptr;
+  int nw = nch <= 4 * mt_round(4, pre) ? 4 : 8;                      // a wave's run in one round of loads where eight waves allow it
+  while (nw < 16 && tiles * nw < 2 * (int64_t)num_cus() && nch >= 4 * nw) nw *= 2;   // few tiles: more waves per tile
+  return nw;
+}
+
+template <int NW, bool PRE, bool PW>
+static int launch_conv_mt_t(const ConvArgs& a, hipStream_t st) {
+  const int tiles_m = (a.M + 15) / 16, tiles_n = (a.Cout + 15) / 16;
+  ConvArgs b = a;
+  b.fd_howo = make_fastdiv(a.Ho * a.Wo);
+  b.fd_wo = make_fastdiv(a.Wo);
+  b.fd_kw = make_fastdiv(a.KW);
+  b.fd_taps = make_fastdiv(a.KH * a.KW);
+  const unsigned grid = (unsigned)(((tiles_n + 7) / 8) * 8 * tiles_m);
+  hipLaunchKernelGGL((conv_mt_kernel<NW, PRE, PW>), dim3(grid), dim3(NW * 64), 0, st, b, tiles_m, tiles_n);
+  DIF_HIP(hipGetLastError());
+  static const std::string label = std::string("conv_mt_kernel<16x16,") + (PW ? "pointwise" : "gather") + (PRE ? ",preact" : "") +
+                                   "," + std::to_string(NW) + " waves>";
+  g_last_kernel = label.c_str();
+  return 0;
+}
+template <int NW>
+static int launch_conv_mt_n(const ConvArgs& a, hipStream_t st) {
+  const bool pw1 = a.KH == 1 && a.KW == 1 && a.pad_t == 0 && a.pad_l == 0 && a.Cin % BK == 0;
+  if (a.pre_scale) return pw1 ? launch_conv_mt_t<NW, true, true>(a, st) : launch_conv_mt_t<NW, true, false>(a, st);
+  return pw1 ? launch_conv_mt_t<NW, false, true>(a, st) : launch_conv_mt_t<NW, false, false>(a, st);
+}
+static int launch_conv_mt(const ConvArgs& a, int nw, hipStream_t st) {
+  return nw == 4 ? launch_conv_mt_n<4>(a, st) : (nw == 8 ? launch_conv_mt_n<8>(a, st) : launch_conv_mt_n<16>(a, st));
+}
+
 template <int AMP>
 static int launch_conv_skp(const ConvArgs& a, int S, hipStream_t st) {
   using T = Tile<1, 1>;
@@ -2472,6 +2515,7 @@ static int launch_conv_skp(const ConvArgs& a, int S, hipStream_t st) {
 template <class T>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
   if constexpr (T::BM == 64 && T::BN == 64) {
+    if (const int nw = mt_plan(a)) return launch_conv_mt(a, nw, st);
     if (const int S = sk2_plan(a)) {
       // 3x3 / stride 1 layers whose linear halo patch fits: the B-direct patch mainloop (dbg bit 16384 keeps the gather: A/B)
       const int emax = (!(a.off & CONV_OFF_BD) && a.w_frag && !(a.dbg & 16384)) ? patch_applies(a) : 0;

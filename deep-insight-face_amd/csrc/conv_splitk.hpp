@@ -372,6 +372,75 @@ __global__ __launch_bounds__(T::NT, 2) void conv_skp_kernel(const ConvArgs a, in
   }
 }
 
+// The layer's epilogue for FOUR consecutive rows of ONE output channel (what a lane holds of an MFMA accumulator fragment),
+// in two halves: prefetch() requests everything but the sums (constants, shortcut values) -- call it before the sums are
+// waited for --, finish() applies  act(v scale + shift) (+ shortcut) -> y,  act2(y scale2 + shift2) -> y2  with conv_epilogue's
+// arithmetic, element by element, and stores through the output view (channel slice / interior of a larger map / even
+// pixels only).
+struct SkEpi {
+  float sc, sh, al, sc2, sh2, al2;
+  float rres[4];
+  int img[4], ho[4], wo[4];
+  int row0, c;
+  bool col_ok, plain_out;
+  __device__ __forceinline__ void prefetch(const ConvArgs& a, int row0_, int c_) {
+    row0 = row0_;
+    c = c_;
+    col_ok = c < a.Cout;
+    const int cc = col_ok ? c : 0;
+    sc = a.scale ? a.scale[cc] : 1.f;
+    sh = a.shift ? a.shift[cc] : 0.f;
+    al = a.alpha ? a.alpha[cc] : 0.f;
+    sc2 = a.scale2 ? a.scale2[cc] : 1.f;
+    sh2 = a.shift2 ? a.shift2[cc] : 0.f;
+    al2 = a.alpha2 ? a.alpha2[cc] : 0.f;
+    plain_out = (a.y_H == a.Ho && a.y_W == a.Wo && a.y_oy == 0 && a.y_ox == 0);
+    const bool strided_res = (a.res_stride != 1 || a.res_H != a.Ho || a.res_W != a.Wo);
+    const bool need_pix = !plain_out || a.y_sub || (a.res && strided_res);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = row0 + e;
+      img[e] = ho[e] = wo[e] = 0;
+      rres[e] = 0.f;
+      if (row < a.M && col_ok) {
+        if (need_pix) {
+          int rr;
+          a.fd_howo.divmod(row, img[e], rr);
+          a.fd_wo.divmod(rr, ho[e], wo[e]);
+        }
+        if (a.res) {
+          int64_t ri = row;
+          if (strided_res) ri = ((int64_t)img[e] * a.res_H + (int64_t)ho[e] * a.res_stride) * a.res_W + (int64_t)wo[e] * a.res_stride;
+          rres[e] = a.res[ri * a.Cout + c];
+        }
+      }
+    }
+  }
+  __device__ __forceinline__ void finish(const ConvArgs& a, const f32x4& sum) const {
+    if (!col_ok) return;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = row0 + e;
+      if (row >= a.M) continue;
+      float t = fmaf(sum[e], sc, sh);
+      t = apply_act(t, a.act, al);
+      if (a.res) t += rres[e];
+      const float t2 = apply_act(fmaf(t, sc2, sh2), a.act2, al2);
+      int64_t o;
+      if (plain_out) o = (int64_t)row * a.y_ld + a.y_coff + c;
+      else o = (((int64_t)img[e] * a.y_H + ho[e] + a.y_oy) * a.y_W + wo[e] + a.y_ox) * a.y_ld + a.y_coff + c;
+      int64_t oy = o;
+      bool y_on = a.y != nullptr;
+      if (a.y_sub) {
+        y_on = y_on && !((ho[e] | wo[e]) & 1);
+        oy = (((int64_t)img[e] * ((a.Ho + 1) >> 1) + (ho[e] >> 1)) * ((a.Wo + 1) >> 1) + (wo[e] >> 1)) * a.Cout + c;
+      }
+      if (y_on) a.y[oy] = t;
+      if (a.y2) a.y2[o] = t2;
+    }
+  }
+};
+
 // one wave per (tile, wave fragment w, quarter q); 64-thread blocks
 __global__ __launch_bounds__(64) void conv_sk_reduce_kernel(const ConvArgs a, int S, int tiles_n) {
   const int lane = threadIdx.x;
@@ -379,36 +448,10 @@ __global__ __launch_bounds__(64) void conv_sk_reduce_kernel(const ConvArgs a, in
   const int q = item & 3, w = (item >> 2) & 3, tile = item >> 4;
   const int mt = tile / tiles_n, nt = tile - mt * tiles_n;
   const float* slab = a.sk_slab + (int64_t)tile * S * 4096 + (q * 256 + w * 64 + lane) * 4;
-  // the fragment's coordinates: register e of quarter q is row 8 q + 4 (lane >> 5) + e, column lane & 31
-  const int c = nt * 64 + (w & 1) * 32 + (lane & 31);
-  const int row0 = mt * 64 + (w >> 1) * 32 + q * 8 + (lane >> 5) * 4;
-  const bool col_ok = c < a.Cout;
-  const int cc = col_ok ? c : 0;
-  // everything the epilogue needs besides the partial sums is requested FIRST: one memory latency for the launch, not three
-  const float sc = a.scale ? a.scale[cc] : 1.f, sh = a.shift ? a.shift[cc] : 0.f, al = a.alpha ? a.alpha[cc] : 0.f;
-  const float sc2 = a.scale2 ? a.scale2[cc] : 1.f, sh2 = a.shift2 ? a.shift2[cc] : 0.f, al2 = a.alpha2 ? a.alpha2[cc] : 0.f;
-  const bool plain_out = (a.y_H == a.Ho && a.y_W == a.Wo && a.y_oy == 0 && a.y_ox == 0);
-  const bool strided_res = (a.res_stride != 1 || a.res_H != a.Ho || a.res_W != a.Wo);
-  const bool need_pix = !plain_out || a.y_sub || (a.res && strided_res);
-  float rres[4] = {0.f, 0.f, 0.f, 0.f};
-  int img[4], ho[4], wo[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int row = row0 + e;
-    img[e] = ho[e] = wo[e] = 0;
-    if (row < a.M && col_ok) {
-      if (need_pix) {
-        int rr;
-        a.fd_howo.divmod(row, img[e], rr);
-        a.fd_wo.divmod(rr, ho[e], wo[e]);
-      }
-      if (a.res) {
-        int64_t ri = row;
-        if (strided_res) ri = ((int64_t)img[e] * a.res_H + (int64_t)ho[e] * a.res_stride) * a.res_W + (int64_t)wo[e] * a.res_stride;
-        rres[e] = a.res[ri * a.Cout + c];
-      }
-    }
-  }
+  // the fragment's coordinates: register e of quarter q is row 8 q + 4 (lane >> 5) + e, column lane & 31.
+  // Everything the epilogue needs besides the partial sums is requested FIRST: one memory latency for the launch, not three
+  SkEpi epi;
+  epi.prefetch(a, mt * 64 + (w >> 1) * 32 + q * 8 + (lane >> 5) * 4, nt * 64 + (w & 1) * 32 + (lane & 31));
   f32x4 sum;
   {
     constexpr int CH = 16;                                    // partials in flight per lane
@@ -436,25 +479,5 @@ __global__ __launch_bounds__(64) void conv_sk_reduce_kernel(const ConvArgs a, in
       s0 += n;
     }
   }
-  if (!col_ok) return;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int row = row0 + e;
-    if (row >= a.M) continue;
-    float t = fmaf(sum[e], sc, sh);
-    t = apply_act(t, a.act, al);
-    if (a.res) t += rres[e];
-    const float t2 = apply_act(fmaf(t, sc2, sh2), a.act2, al2);
-    int64_t o;
-    if (plain_out) o = (int64_t)row * a.y_ld + a.y_coff + c;
-    else o = (((int64_t)img[e] * a.y_H + ho[e] + a.y_oy) * a.y_W + wo[e] + a.y_ox) * a.y_ld + a.y_coff + c;
-    int64_t oy = o;
-    bool y_on = a.y != nullptr;
-    if (a.y_sub) {
-      y_on = y_on && !((ho[e] | wo[e]) & 1);
-      oy = (((int64_t)img[e] * ((a.Ho + 1) >> 1) + (ho[e] >> 1)) * ((a.Wo + 1) >> 1) + (wo[e] >> 1)) * a.Cout + c;
-    }
-    if (y_on) a.y[oy] = t;
-    if (a.y2) a.y2[o] = t2;
-  }
+  epi.finish(a, sum);
 }

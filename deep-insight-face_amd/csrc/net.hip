@@ -878,7 +878,7 @@ static void fold(const Net* net, const BNRef& bn, int bias, int C, std::vector<f
 // pick between kernel families the parity tests compare)
 // every key set_option accepts (dif_net_option_name: include/dif.h documents each one, and a test holds it to that)
 const char* const* Net::option_names() {
-  static const char* const names[] = {"pipe", "bdp", "stem", "patch", "patch2d", "bd", "t2", "tn", "sk2", "pw", "bf16x3",
+  static const char* const names[] = {"pipe", "bdp", "stem", "patch", "patch2d", "bd", "t2", "tn", "sk2", "mt", "pw", "bf16x3",
                                       "bf_terms", "ysub", "lane_split", "lane_prio", "dbg", nullptr};
   return names;
 }
@@ -907,6 +907,7 @@ int Net::set_option(const char* key, int value) {
   if (!strcmp(key, "t2")) return flag(CONV_OFF_T2);
   if (!strcmp(key, "tn")) return flag(CONV_OFF_TN);
   if (!strcmp(key, "sk2")) return flag(CONV_OFF_SK2);
+  if (!strcmp(key, "mt")) return flag(CONV_OFF_MT);
   if (!strcmp(key, "pw")) {                                 // conv_pw_kernel is OFF by default: the bit means "on" for this family
     // its fragment-order weight copy is built at finalize only when the option is on by then (it doubled the
     // pointwise weights of every net for a path that is off by default): on -> off any time, off -> on before finalize
@@ -1049,6 +1050,30 @@ int Net::finalize(int mb) {
         if ((uint64_t)frag.size() * 4 < 0xFFFFFFF0ull) {
           if (upload(this, frag, &op.d_w_frag)) return -1;
           op.w_frag_bytes = (uint32_t)(frag.size() * 4);
+        }
+      }
+      // 16-column fragment order for the one-image kernel (conv_minitile.hpp): every layer it can take -- pointwise layers
+      // and multi-tap layers with whole 32-channel slices.  A (column tile, 16-k chunk) is 1 KB, lane l at byte 16 l: the
+      // kernel's B loads are whole 128-byte lines (from the [Cout][Kpad] matrix a wave instruction touched 16 half lines)
+      op.d_w_f16 = nullptr;
+      op.w_f16_bytes = 0;
+      {
+        const bool pw1 = op.KH == 1 && op.KW == 1 && op.pad_t == 0 && op.pad_l == 0 && op.Cin % BK == 0;
+        if ((pw1 || (op.k_order == 1 && op.Cin % BK == 0)) && !op.d_w_raw) {
+          const int nch = op.Kpad / 16, NT16 = (op.Cout + 15) / 16;
+          std::vector<float> f16((size_t)NT16 * nch * 256, 0.f);
+          size_t o = 0;
+          for (int ct = 0; ct < NT16; ++ct)
+            for (int c = 0; c < nch; ++c)
+              for (int ln = 0; ln < 64; ++ln)
+                for (int t = 0; t < 4; ++t, ++o) {
+                  const int row = ct * 16 + (ln & 15);
+                  if (row < op.Cout) f16[o] = packed[(size_t)row * op.Kpad + (size_t)c * 16 + 4 * (ln >> 4) + t];
+                }
+          if ((uint64_t)f16.size() * 4 < 0xFFFFFFF0ull) {
+            if (upload(this, f16, &op.d_w_f16)) return -1;
+            op.w_f16_bytes = (uint32_t)(f16.size() * 4);
+          }
         }
       }
       fold(this, op.bn, op.bias, op.Cout, &scale, &shift);
@@ -1276,6 +1301,8 @@ int Net::run_op(const Op& op, Lane& L, const void* xin, int n, int layout, int d
       a.w3f_bytes = op.w3f_bytes;
       a.w_frag = op.d_w_frag;
       a.w_frag_bytes = op.w_frag_bytes;
+      a.w_f16 = op.d_w_f16;
+      a.w_f16_bytes = op.w_f16_bytes;
       a.bf_terms = bf_terms;
       a.y = ptr(op.y);
       a.y2 = ptr(op.y2);

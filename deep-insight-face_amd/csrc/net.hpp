@@ -69,6 +69,8 @@ struct Op {
   float* d_w_dense = nullptr;
   float* d_w_frag = nullptr;  // the matrix in MFMA-fragment order (ConvArgs::w_frag), 3x3 / stride 1 layers on the f32 path
   uint32_t w_frag_bytes = 0;
+  float* d_w_f16 = nullptr;   // ... and in the 16-column fragment order of the one-image kernel (ConvArgs::w_f16), layers it can take
+  uint32_t w_f16_bytes = 0;
   void* d_w3f = nullptr;      // compute mode bf16x3: the split-bf16 planes in MFMA-fragment order (ConvArgs::w3f), 3x3 / stride 1 layers
   uint32_t w3f_bytes = 0;
   float* d_scale = nullptr;

@@ -38,7 +38,7 @@ inline FastDiv make_fastdiv(int d) {
   return f;
 }
 
-enum { CONV_OFF_PATCH = 1, CONV_OFF_PATCH2D = 2, CONV_OFF_BD = 4, CONV_OFF_PW = 8, CONV_OFF_T2 = 16, CONV_OFF_TN = 32, CONV_OFF_SK2 = 64 };   // PW: inverted (bit set = ON)
+enum { CONV_OFF_PATCH = 1, CONV_OFF_PATCH2D = 2, CONV_OFF_BD = 4, CONV_OFF_PW = 8, CONV_OFF_T2 = 16, CONV_OFF_TN = 32, CONV_OFF_SK2 = 64, CONV_OFF_MT = 128 };   // PW: inverted (bit set = ON)
 
 struct ConvArgs {
   const float* x;       // [N,H,W,Cin] NHWC
@@ -46,6 +46,9 @@ struct ConvArgs {
   const float* w_frag;  // the same matrix in MFMA-fragment order for the B-direct patch mainloop (conv.hip), or null:
                         // [ceil(Cout/32)][Kpad/32][s 2][u 2][h 2][n 32][t 4] <- w[32 nt + n][32 ks + 16 s + 8 h + 4 u + t]
   uint32_t w_frag_bytes;
+  const float* w_f16;   // the same matrix in the one-image kernel's order (conv_minitile.hpp), or null:
+                        // [ceil(Cout/16)][Kpad/16][lane 64][t 4] <- w[16 ct + (lane & 15)][16 c + 4 (lane >> 4) + t]
+  uint32_t w_f16_bytes;
   const void* w3f;      // split-bf16 mode, 3x3 / stride 1 layers: the three bf16 planes in MFMA-fragment order (conv.hip:
   uint32_t w3f_bytes;   // gemm_mainloop_patch_bf3), [ceil(Cout/32)][Kpad/32][s 2][plane 3][lane 64][8]
   int bf_terms;         // 3 (or 0): all three planes, six products; 2: the hi and mid planes only, three products ("bf16x2")

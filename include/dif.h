@@ -216,6 +216,9 @@ int dif_net_finalize(dif_net* net, int max_batch);
  *   "sk2"        1 (default): layers with few tiles and a long K loop -- the reference's own call shapes, ONE image
  *                (predictions.py:152-156) or a batch of 12 (scripts/insight_face.py:112) -- run as split-K partials +
  *                a reduce / epilogue launch (conv_splitk.hpp); 0: round 4's persistent stream-K grid
+ *   "mt"         1 (default): at ONE image per call (predictions.py:152-156) a layer runs in one launch on 16 x 16 tiles,
+ *                operands straight from L2 into the MFMA registers, K split over the block's waves (conv_minitile.hpp);
+ *                0: the split-K pair / the large-batch kernels
  *   "pw"         0 (default); 1 (before dif_net_finalize: it lays the pointwise weights out once more; back to 0 any time):
  *                1x1 / stride 1 layers run on the barrier-free pointwise kernel (conv_pw_kernel: bit-identical, slower
  *                inside the two-lane executor)

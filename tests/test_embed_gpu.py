@@ -586,13 +586,54 @@ def test_splitk_path_equals_streamk_path(cuda, arch, head, emd, shape, n):
     x = torch.from_numpy(rng.integers(0, 256, (n,) + shape, dtype=np.uint8)).cuda()
     m = DifEmbedder(arch, head, emd, shape, max_batch=n).init_synthetic(13)
     m.set_input_transform(scale=1 / 255.)
+    m.set_option('mt', 0)                      # (the one-image kernel would take most layers at n = 1: its own test below)
     a = m.embed(x)
     a2 = m.embed(x)
     kernels = [k for _, k, _, _ in m.profile(x)]
-    assert any(k.startswith('conv_sk_kernel') for k in kernels), kernels
+    assert any(k.startswith('conv_sk') for k in kernels), kernels
+    m.set_option('dbg', 16384)                 # the gather form of the split-K block where the patch form ran
+    g = m.embed(x)
+    m.set_option('dbg', 0)
     m.set_option('sk2', 0)
     b = m.embed(x)
-    assert not any(k.startswith('conv_sk_kernel') for _, k, _, _ in m.profile(x))
+    assert not any(k.startswith('conv_sk') for _, k, _, _ in m.profile(x))
+    g = g if isinstance(g, list) else [g]
+    for tg, tb in zip(g, b if isinstance(b, list) else [b]):
+        assert float((tg - tb).abs().max()) <= (2e-5 if arch == 'yolov3' else 4e-6) * max(float(tb.abs().max()), 1.0), arch
+    a, a2, b = [t if isinstance(t, list) else [t] for t in (a, a2, b)]
+    for ta, ta2, tb in zip(a, a2, b):
+        assert torch.equal(ta, ta2)                                       # deterministic
+        scale = max(float(tb.abs().max()), 1.0)
+        assert float((ta - tb).abs().max()) <= (2e-5 if arch == 'yolov3' else 4e-6) * scale, arch
+    m.close()
+
+
+@pytest.mark.parametrize('arch,head,emd,shape,n', [('resnet', 'v2', 512, (112, 112, 3), 1), ('resnet', 'v1', 128, (112, 112, 3), 2),
+                                                   ('iresnet50', 'v2', 512, (112, 112, 3), 1), ('iresnet100', 'v2', 512, (112, 112, 3), 1),
+                                                   ('iresnet50', 'v2', 512, (112, 112, 3), 3), ('mobilenet', 'v2', 512, (112, 112, 3), 1),
+                                                   ('vgg16', 'v2', 512, (112, 112, 3), 1), ('resnet', 'v2', 512, (96, 96, 3), 1),
+                                                   ('yolov3', 'v3', 1, (416, 416, 3), 1)])
+def test_one_image_kernel_equals_other_paths(cuda, arch, head, emd, shape, n):
+    """Round 5: at ONE image per call (predictions.py:152-156, the reference's own call shape) a layer runs in one launch on
+    16 x 16 tiles (conv_mt_kernel: operands straight from L2 into v_mfma_f32_16x16x4_f32, K split over the block's waves,
+    their sums added in wave order); option 'mt' = 0 sends the same layers to the split-K pair / the large-batch kernels.
+    Same products, another fixed summation order: embeddings agree to float32 rounding and are bit-identical run to run.
+    Covers pre-activation on both loaders (ResNet50V2), PReLU + two outputs + sub-sampled first outputs + strided
+    shortcuts + stride-2 3x3 layers (IResNet), 1x1 expansions and ReLU6 (MobileNetV2), ragged 16-pixel tiles (a 96 x 96
+    input: 6 x 6, 3 x 3 maps), a batch of 2-3 where only the small layers qualify, concat views / 18-channel heads (YOLOv3)."""
+    import torch
+    from deep_insight_face.networks.triplet import DifEmbedder
+    rng = np.random.default_rng(n * 11 + len(arch))
+    x = torch.from_numpy(rng.integers(0, 256, (n,) + shape, dtype=np.uint8)).cuda()
+    m = DifEmbedder(arch, head, emd, shape, max_batch=n).init_synthetic(17)
+    m.set_input_transform(scale=1 / 255.)
+    a = m.embed(x)
+    a2 = m.embed(x)
+    kernels = [k for _, k, _, _ in m.profile(x)]
+    assert any(k.startswith('conv_mt_kernel') for k in kernels), kernels
+    m.set_option('mt', 0)
+    b = m.embed(x)
+    assert not any(k.startswith('conv_mt_kernel') for _, k, _, _ in m.profile(x))
     a, a2, b = [t if isinstance(t, list) else [t] for t in (a, a2, b)]
     for ta, ta2, tb in zip(a, a2, b):
         assert torch.equal(ta, ta2)                                       # deterministic
