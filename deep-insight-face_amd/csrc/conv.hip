@@ -2467,6 +2467,7 @@ static int launch_conv_mt_t(const ConvArgs& a, hipStream_t st) {
   b.fd_kw = make_fastdiv(a.KW);
   b.fd_taps = make_fastdiv(a.KH * a.KW);
   const unsigned grid = (unsigned)(((tiles_n + 7) / 8) * 8 * tiles_m);
+  // (asking for more than half a CU's LDS, so that no CU is dealt two blocks while another idles: no effect, r05_ablation item 5)
   hipLaunchKernelGGL((conv_mt_kernel<NW, PRE, PW>), dim3(grid), dim3(NW * 64), 0, st, b, tiles_m, tiles_n);
   DIF_HIP(hipGetLastError());
   static const std::string label = std::string("conv_mt_kernel<16x16,") + (PW ? "pointwise" : "gather") + (PRE ? ",preact" : "") +

@@ -135,8 +135,7 @@ int dif_gallery_set(dif_gallery* h, const float* rows_dev, int64_t n, int64_t in
   g.index_base = index_base;
   g.rows2_valid = g.rows1_valid = false;
   if (n == 0) return 0;
-  DIF_HIP(hipMemcpyAsync(g.rows, rows_dev, (size_t)n * g.d * sizeof(float), hipMemcpyDeviceToDevice, st));
-  return gallery_norms(&g, st);
+  return gallery_norms(&g, rows_dev, st);                   // one pass: the copy, the norms and the filter's bf16 copy
 }
 
 int dif_gallery_reserve(dif_gallery* h, int64_t capacity, void* stream) {
@@ -197,10 +196,9 @@ int dif_gallery_update(dif_gallery* h, const float* rows_dev, int64_t n, int64_t
                      (long long)first_row, (long long)(first_row + n), (long long)g.cap);
   if (n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  DIF_HIP(hipMemcpyAsync(g.rows + (size_t)first_row * g.d, rows_dev, (size_t)n * g.d * sizeof(float), hipMemcpyDeviceToDevice, st));
   const int64_t old_n = g.n;
   if (first_row + n > g.n) g.n = first_row + n;
-  return gallery_update_rows(&g, first_row, n, old_n, st);
+  return gallery_update_rows(&g, rows_dev, first_row, n, old_n, st);
 }
 
 int64_t dif_gallery_size(const dif_gallery* h) { return h ? h->g.n : 0; }

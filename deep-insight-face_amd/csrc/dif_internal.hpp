@@ -57,9 +57,9 @@ struct Gallery {
   bool clamp_nan = false;          // report distance 0 / 1 instead of the reference's NaN (dif_gallery_set_option)
 };
 
-int gallery_norms(Gallery* g, hipStream_t st);
+int gallery_norms(Gallery* g, const float* src, hipStream_t st);   // src: the caller's rows (copied into g->rows in the same pass), or null
 int gallery_split_copy(Gallery* g, hipStream_t st);   // (re)builds rows2 when the option asks for it; never fatal
-int gallery_update_rows(Gallery* g, int64_t first, int64_t count, int64_t old_n, hipStream_t st);   // after rows [first, first+count) changed
+int gallery_update_rows(Gallery* g, const float* src, int64_t first, int64_t count, int64_t old_n, hipStream_t st);   // rows [first, first+count) <- src
 int match_run(Gallery* g, const float* probes, int B, int metric, int64_t* idx_out, float* dist_out,
               float* key_out, hipStream_t st);
 int pairwise_run(const float* e1, int64_t n1, const float* e2, int64_t n2, int D, int metric, float* out,
