@@ -1,4 +1,4 @@
-"""Copies the round's rocprofv3 summaries from gpurun_out/r04/ into profiles/ and prints the cross-checks
+"""Copies the round's rocprofv3 summaries from gpurun_out/r05/ into profiles/ and prints the cross-checks
 the bench line's `roofline` rests on: per forward, the sum of the conv kernel durations in the kernel-trace stats
 (one lane: no overlap) vs the HIP-event forward time reported by bench.py, and the frac recomputed from them."""
 import csv
@@ -9,9 +9,9 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, 'gpurun_out', 'r04')
+OUT = os.path.join(ROOT, 'gpurun_out', 'r05')
 PROF = os.path.join(ROOT, 'profiles')
-R = 'r04'
+R = 'r05'
 PEAK = 157.3
 
 
@@ -26,7 +26,8 @@ def jl(path):
 def conv_ms(stats_csv):
     ns = calls = 0
     for r in csv.DictReader(open(stats_csv)):
-        if any(k in r['Name'] for k in ('conv_igemm_kernel', 'conv_pipe_kernel', 'conv_bdp_kernel', 'conv_tn_kernel', 'conv_t2_kernel', 'conv_pw_kernel', 'stem_mfma_kernel', 'stem3x3_kernel')):
+        if any(k in r['Name'] for k in ('conv_igemm_kernel', 'conv_pipe_kernel', 'conv_bdp_kernel', 'conv_tn_kernel', 'conv_t2_kernel', 'conv_pw_kernel', 'conv_sk_kernel', 'conv_skp_kernel', 'conv_sk_reduce_kernel', 'conv_mt_kernel',
+                                         'stem_mfma_kernel', 'stem3x3_kernel')):
             ns += float(r['TotalDurationNs'])
             calls += int(r['Calls'])
     return ns / 1e6, calls
@@ -54,8 +55,15 @@ def main():
                      ('layers_r100_bf16x2.txt', 'r100_b256_bf16x2_layers.txt'), ('layers_yolov3.txt', 'yolov3_b64_layers.txt'),
                      ('latency.txt', 'latency.txt'), ('batch_sweep.txt', 'batch_sweep.txt'), ('bf_tier_gates.txt', 'bf_tier_gates.txt'),
                      ('match_ab.txt', 'match_filter_ab.txt'), ('match_pmc_table.txt', 'match_wave_states.txt'),
-                     ('match_traffic.txt', 'match_fabric_traffic.txt')):
+                     ('match_traffic.txt', 'match_fabric_traffic.txt'), ('launch_modes.txt', 'launch_modes.txt'),
+                     ('gallery_set.txt', 'gallery_set.txt'), ('trace_r100_b1.txt', 'r100_b1_block_trace.txt'),
+                     ('trace_r100_b8.txt', 'r100_b8_block_trace.txt'), ('trace_r50_b1.txt', 'r50_b1_block_trace.txt')):
         cp(src, R + '_' + src.replace(src, dst))
+    for a, short in (('iresnet100', 'r100'), ('resnet', 'r50')):
+        for b in (1, 8, 32):
+            cp('layers_%s_b%d.txt' % (a, b), '%s_%s_b%d_layers.txt' % (R, short, b))
+            if os.path.exists(os.path.join(OUT, 'ksb_%s_%d.txt' % (a, b))):
+                cp('ksb_%s_%d.txt' % (a, b), '%s_%s_b%d_kernel_stats.txt' % (R, short, b))
     # forwards per profiled run, in units of the workload's batch: bench.py reports them (`forwards_in_process`:
     # steps + warmup, the per-layer profile, the warm-up and the stamped forward of the clock measurement, and the
     # batch-256 forwards of the default workload)
