@@ -418,21 +418,27 @@ int stem3x3_run(const float* x, const float* w_hwio, const float* scale, const f
 // Conv2D(emd, 1) -> Dropout (identity) -> Flatten -> Dense(emd) -> l2_normalize, two images per block.  About
 // 0.5 MMAC per image against 2 MB of weights that stay in L2: bound by launch and latency, so what matters is
 // that it is ONE launch (it was four) and that the weight reads are coalesced along the output axis.
-__global__ __launch_bounds__(256) void gdc_tail_kernel(const float* __restrict__ x, const float* __restrict__ wdw,
+// KSPLIT = K slices of the two matrix-vector products = threads / 128.  2 (256 threads) for whole batches: two images per
+// block, many blocks.  8 (1024 threads) for one or two images (round 5): the block is alone on the chip and streams the two
+// 1 MB weight matrices through ONE CU -- four times the loads in flight (34 -> ~15 us at batch 1); same sums in another
+// (fixed) order.
+template <int KSPLIT>
+__global__ __launch_bounds__(128 * KSPLIT) void gdc_tail_kernel(const float* __restrict__ x, const float* __restrict__ wdw,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        const float* __restrict__ wpw, const float* __restrict__ wd,
                                                        float* __restrict__ y, int N, int HW, int E, float eps) {
   constexpr int C = 512;
   __shared__ float a[2][C];            // depthwise + BN output of the block's two images
   __shared__ float b[2][1024];         // 1x1 convolution output
-  __shared__ float part[2][2][1024];   // [K half][image][j]: partial sums of the two matrix-vector products
-  __shared__ float red[2][4];
+  __shared__ float part[KSPLIT][2][1024];   // [K slice][image][j]: partial sums of the two matrix-vector products
+  __shared__ float red[2][2 * KSPLIT];
+  constexpr int NT = 128 * KSPLIT;
   const int tid = threadIdx.x;
   const int64_t n0 = (int64_t)blockIdx.x * 2;
   const bool two = n0 + 1 < N;
   const float* x0 = x + n0 * HW * C;
   const float* x1 = x + (two ? n0 + 1 : n0) * HW * C;
-  for (int c = tid; c < C; c += 256) {
+  for (int c = tid; c < C; c += NT) {
     float s0 = 0.f, s1 = 0.f;
     for (int p = 0; p < HW; ++p) {
       const float w = wdw[p * C + c];
@@ -446,9 +452,9 @@ __global__ __launch_bounds__(256) void gdc_tail_kernel(const float* __restrict__
   __syncthreads();
   // y[j] = sum_k v[k] * W[k][j] for both images: a thread owns four adjacent outputs (one 16-byte weight load per k)
   // and one half of the k range; sixteen loads in flight per thread keep the L2 round trip covered
-  const int half = tid >> 7, jq = tid & 127;
+  const int half = tid >> 7, jq = tid & 127;                // `half`: this thread's K slice
   auto gemv = [&](const float* W, int K, const float* v0, const float* v1) {
-    const int k0 = half * (K / 2), k1 = k0 + K / 2;
+    const int k0 = half * (K / KSPLIT), k1 = k0 + K / KSPLIT;
     for (int j = 4 * jq; j < E; j += 512) {
       f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 16
@@ -467,19 +473,34 @@ __global__ __launch_bounds__(256) void gdc_tail_kernel(const float* __restrict__
   };
   gemv(wpw, C, a[0], a[1]);
   __syncthreads();
-  for (int j = tid; j < E; j += 256) {
-    b[0][j] = part[0][0][j] + part[1][0][j];
-    b[1][j] = part[0][1][j] + part[1][1][j];
+  for (int j = tid; j < E; j += NT) {
+    float s0 = part[0][0][j], s1 = part[0][1][j];
+#pragma unroll
+    for (int k = 1; k < KSPLIT; ++k) {
+      s0 += part[k][0][j];
+      s1 += part[k][1][j];
+    }
+    b[0][j] = s0;
+    b[1][j] = s1;
   }
   __syncthreads();
   gemv(wd, E, b[0], b[1]);
   __syncthreads();
-  float o0[4], o1[4], ss0 = 0.f, ss1 = 0.f;
+  constexpr int QN = 1024 / NT;                           // outputs per thread (E <= 1024)
+  float o0[QN], o1[QN], ss0 = 0.f, ss1 = 0.f;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int j = tid + 256 * q;
-    o0[q] = j < E ? part[0][0][j] + part[1][0][j] : 0.f;
-    o1[q] = j < E ? part[0][1][j] + part[1][1][j] : 0.f;
+  for (int q = 0; q < QN; ++q) {
+    const int j = tid + NT * q;
+    o0[q] = o1[q] = 0.f;
+    if (j < E) {
+      o0[q] = part[0][0][j];
+      o1[q] = part[0][1][j];
+#pragma unroll
+      for (int k = 1; k < KSPLIT; ++k) {
+        o0[q] += part[k][0][j];
+        o1[q] += part[k][1][j];
+      }
+    }
     ss0 = fmaf(o0[q], o0[q], ss0);
     ss1 = fmaf(o1[q], o1[q], ss1);
   }
@@ -493,11 +514,17 @@ __global__ __launch_bounds__(256) void gdc_tail_kernel(const float* __restrict__
     red[1][tid >> 6] = ss1;
   }
   __syncthreads();
-  const float inv0 = 1.f / sqrtf(fmaxf(red[0][0] + red[0][1] + red[0][2] + red[0][3], eps));
-  const float inv1 = 1.f / sqrtf(fmaxf(red[1][0] + red[1][1] + red[1][2] + red[1][3], eps));
+  float t0 = red[0][0], t1 = red[1][0];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int j = tid + 256 * q;
+  for (int k = 1; k < 2 * KSPLIT; ++k) {
+    t0 += red[0][k];
+    t1 += red[1][k];
+  }
+  const float inv0 = 1.f / sqrtf(fmaxf(t0, eps));
+  const float inv1 = 1.f / sqrtf(fmaxf(t1, eps));
+#pragma unroll
+  for (int q = 0; q < QN; ++q) {
+    const int j = tid + NT * q;
     if (j < E) {
       y[n0 * E + j] = o0[q] * inv0;
       if (two) y[(n0 + 1) * E + j] = o1[q] * inv1;
@@ -509,8 +536,11 @@ int gdc_tail_run(const float* x, const float* w_dw, const float* scale, const fl
                  const float* w_dense, float* y, int N, int HW, int E, float eps, hipStream_t st) {
   if (N == 0) return 0;
   if (E > 1024 || E % 8 != 0) return set_error("gdc_tail: emd %d must be a multiple of 8, at most 1024", E);
-  hipLaunchKernelGGL(gdc_tail_kernel, dim3((unsigned)((N + 1) / 2)), dim3(256), 0, st, x, w_dw, scale, shift, w_pw, w_dense,
-                     y, N, HW, E, eps);
+  if (N <= 2)
+    hipLaunchKernelGGL(gdc_tail_kernel<8>, dim3(1), dim3(1024), 0, st, x, w_dw, scale, shift, w_pw, w_dense, y, N, HW, E, eps);
+  else
+    hipLaunchKernelGGL(gdc_tail_kernel<2>, dim3((unsigned)((N + 1) / 2)), dim3(256), 0, st, x, w_dw, scale, shift, w_pw, w_dense,
+                       y, N, HW, E, eps);
   DIF_HIP(hipGetLastError());
   return 0;
 }

@@ -258,7 +258,12 @@ int stem_mfma_run(const float* x, const float* w_hwio, const float* scale, const
   a.y_sub = y_sub;
   a.tiles_h = a.tiles_w = a.tiles = 0;
   if (KH == 3 && stride == 1) return stem_launch<StemCfg<3, 3, 1, 1, 2, 16, 4, 1>>(a, st);
-  if (KH == 7 && stride == 2) return stem_launch<StemCfg<7, 7, 2, 3, 4, 8, 1, 7>>(a, st);
+  if (KH == 7 && stride == 2) {
+    // one or two images (round 5: the reference embeds ONE image per call): the 4 x 56 tiles are 14 blocks per image on a
+    // chip of 256 CUs -- 4 x 8 tiles of one wave each (98 per image) instead; same arithmetic per output pixel
+    if ((int64_t)N * ((Ho + 3) / 4) * ((Wo + 55) / 56) <= 32) return stem_launch<StemCfg<7, 7, 2, 3, 4, 8, 1, 1>>(a, st);
+    return stem_launch<StemCfg<7, 7, 2, 3, 4, 8, 1, 7>>(a, st);
+  }
   return set_error("stem: no kernel for a %dx%d / stride %d first layer", KH, KH, stride);
 }
 
