@@ -106,7 +106,7 @@ def measured_traffic(workload, batch):
     """(HBM bytes per forward of the conv kernels, the committed file they come from) -- rocprofv3 PMC passes
     (FETCH_SIZE doubled + WRITE_SIZE, tools/pmc_traffic.py).  Counters cannot be read from inside the
     process, so this is the committed profile of the same command -- NOT a measurement of this run -- or None."""
-    for rnd in ('r04', 'r03', 'r02', 'r01'):
+    for rnd in ('r05', 'r04', 'r03', 'r02', 'r01'):
         name = '%s_%s_b%d_hbm_traffic.json' % (rnd, workload, batch)
         path = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(path):
