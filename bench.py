@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the embedding + match hot path (BASELINE.json metric: faces/sec).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload r100_1m|r50|r100|r100_arc|frames]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload r100_1m|r50|r100|r100_arc|frames|frames_mtcnn]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -58,6 +58,10 @@ WORKLOADS = {
     'frames': ('resnet', 'v2', 256, 100_000,
                'configs[4]: 256 raw 640x480 frames/GPU -> letterbox -> YOLOv3-face -> best box -> crop 112 -> '
                'ResNet-50V2 embed -> 100k gallery match (the reference ships YOLOv3-face, not MTCNN)'),
+    'frames_mtcnn': ('resnet', 'v2', 256, 100_000,
+                     'configs[4] AS WORDED: 256 raw 640x480 frames/GPU -> MTCNN (P-Net over a 10-scale pyramid, R-Net on 32 and O-Net '
+                     'on 16 candidate slots per frame; static shapes, no host round trip) -> best face -> crop 112 -> ResNet-50V2 '
+                     'embed -> 100k gallery match.  MTCNN is not in the reference: public layer tables, synthetic weights'),
 }
 ARC_CLASSES = 85_742     # MS1MV2 identities
 
@@ -262,6 +266,39 @@ def cpu_baseline(arch, head, gallery_rows, budget_s=12.0):
     }
 
 
+def cpu_baseline_frames_mtcnn(gallery_rows, det_params, n_frames=2):
+    """configs[4] as worded on the host cores: the NumPy restatement of the cascade (oracle/mtcnn.py: area-resampled pyramid,
+    P/R/O-Net as im2col matmuls, float32 NMS) -> area-resampled crop -> ResNet-50V2 on torch-CPU ops -> reference-formula
+    match.  Two frames: the restatement's suppression runs in Python."""
+    sys.path.insert(0, ROOT)
+    from oracle import distance as od
+    from oracle import imageops as oi
+    from oracle import mtcnn as om
+    from oracle import nets, torch_nets
+    from deep_insight_face.networks.weights import synth_params
+    cores, quota = usable_cores()
+    torch.set_num_threads(cores)
+    p = synth_params(nets.model_spec('resnet', 512, 112, 'v2'))
+    rng = np.random.default_rng(1234)
+    frames = rng.integers(0, 256, (n_frames, 480, 640, 3), dtype=np.uint8)
+    gal = rng.standard_normal((gallery_rows, 512)).astype(np.float32)
+    gal /= np.linalg.norm(gal, axis=1, keepdims=True)
+
+    def run(fr):
+        boxes, scores, _ = om.detect(fr, det_params)
+        crops = [oi.crop_resize(f, b[0] if s[0] >= 0 else [0, 0, 640, 480], 8, 112) for f, b, s in zip(fr, boxes, scores)]
+        e = torch_nets.embed(np.stack(crops).astype(np.float32) / np.float32(255), p, 'resnet', 'v2')
+        od.match(e, gal, 1)
+
+    t0 = time.perf_counter()
+    run(frames)
+    dt = time.perf_counter() - t0
+    return {'value': n_frames / dt, 'unit': 'frames/s', 'cores': cores, 'kind': 'port', 'cpu_model': cpu_model_string(),
+            'host_hw_threads': os.cpu_count(), 'cgroup_cpu_quota': quota,
+            'sample': '%d frames 640x480: NumPy restatement of the MTCNN cascade + ResNet-50V2 on torch-CPU ops (%d threads) + '
+                      'reference-formula match vs %d rows, %.2fs' % (n_frames, cores, gallery_rows, dt)}
+
+
 def cpu_baseline_frames(gallery_rows, det_params, n_frames=4):
     """configs[4] on the host cores: PIL letterbox (the reference's own call, detector/yolov3.py:108-119) ->
     YOLOv3-face on torch-CPU ops -> box decode + NMS (oracle/detector.py) -> area-resampled crop (oracle/
@@ -431,6 +468,15 @@ def main():
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
     pipe = None
+    mtcnn = args.workload == 'frames_mtcnn'
+    if mtcnn:
+        from deep_insight_face.detector import run as drun
+        from deep_insight_face.detector import mtcnn as dm
+        det = dm.MtcnnDetector((480, 640), max_batch=64).init_synthetic(2025, logit_scale=1e-3)   # every frame yields a detection
+        dp = None
+        pipe = dm.MtcnnFramePipeline(det, model, None, margin=8)
+        frames = torch.randint(0, 256, (batch, 480, 640, 3), generator=g, dtype=torch.uint8).to(dev)
+        det_ms = []
     if args.workload == 'frames':
         from deep_insight_face.detector import run as drun
         det = drun.yolo_v3_face(1, 416, max_batch=64)
@@ -646,8 +692,8 @@ def main():
                           'the %d conv launches of one %s forward at batch %d%s'
                           % (shares[0][0], 100 * shares[0][1], shares[0][2],
                              sum(1 for _, k, _, _ in prof if k.startswith(is_conv)), arch, batch,
-                             '' if pipe is None else ' + the %d conv launches of the YOLOv3-face detector per chunk of 64 frames'
-                             % sum(1 for _, k, _ in det_ops if k.startswith(is_conv))),
+                             '' if pipe is None else ' + the %d conv launches of the %s detector per chunk of 64 frames'
+                             % (sum(1 for _, k, _ in det_ops if k.startswith(is_conv)), 'MTCNN' if mtcnn else 'YOLOv3-face')),
                 'kernels': [{'kernel': k, 'share': round(sh, 4), 'launches': c} for k, sh, c in shares[:8]],
                 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
@@ -751,7 +797,8 @@ def main():
             out['throughput_mode']['tiers'] = tiers
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = (cpu_baseline(arch, head, gallery_rows) if pipe is None else
-                                   cpu_baseline_frames(gallery_rows, dp))
+                                   (cpu_baseline_frames_mtcnn(gallery_rows, det.get_weights()) if mtcnn else
+                                    cpu_baseline_frames(gallery_rows, dp)))
         if json_fd is None:
             print(json.dumps(out), flush=True)
         else:

@@ -196,9 +196,12 @@ __device__ __forceinline__ void area_pixel(const uint8_t* __restrict__ src, int 
 }
 
 // boxes: [N][4] = left, top, right, bottom in frame pixels (as detector/run.py:114 returns them)
+// N crops; crop n comes from frame n / K (K boxes per frame: dif_crop_resize_multi; K = 1 otherwise); `valid`: per crop, a
+// negative value = an empty slot -> a black crop
 __global__ __launch_bounds__(256) void crop_resize_kernel(const uint8_t* __restrict__ frames, int N, int H, int W,
                                                           const float* __restrict__ boxes, float margin,
-                                                          uint8_t* __restrict__ out, int SW, int SH) {
+                                                          uint8_t* __restrict__ out, int SW, int SH, int K = 1,
+                                                          const float* __restrict__ valid = nullptr) {
   const int64_t total = (int64_t)N * SW * SH;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int x = (int)(i % SW);
@@ -213,12 +216,12 @@ __global__ __launch_bounds__(256) void crop_resize_kernel(const uint8_t* __restr
     int r = (int)fminf(b[2] + mg / 2, (float)W), bt = (int)fminf(b[3] + mg / 2, (float)H);
     uint8_t* o = out + i * 3;
     const int cw = r - l, ch = bt - t;
-    const bool nodet = b[0] != b[0] || b[1] != b[1] || b[2] != b[2] || b[3] != b[3];   // NaN = no detection
+    const bool nodet = b[0] != b[0] || b[1] != b[1] || b[2] != b[2] || b[3] != b[3] || (valid && valid[n] < 0.f);   // NaN = no detection
     if (nodet || !(cw > 0 && ch > 0)) {
       o[0] = o[1] = o[2] = 0;
       continue;
     }
-    const uint8_t* img = frames + n * (int64_t)H * W * 3;
+    const uint8_t* img = frames + (n / K) * (int64_t)H * W * 3;
     area_pixel(img + ((int64_t)t * W + l) * 3, W, cw, ch, SW, SH, x, y, o);
   }
 }
@@ -253,6 +256,19 @@ int dif_crop_resize(const uint8_t* frames_dev, int n, int h, int w, const float*
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(crop_resize_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, frames_dev, n, h, w,
                      boxes_ltrb_dev, margin, out_dev, size, size);
+  DIF_HIP(hipGetLastError());
+  return 0;
+}
+
+int dif_crop_resize_multi(const uint8_t* frames_dev, int n, int h, int w, const float* boxes_ltrb_dev, const float* valid_dev,
+                          int k, float margin, uint8_t* out_dev, int size, void* stream) {
+  if (n < 0 || h <= 0 || w <= 0 || size <= 0 || k < 1) return set_error("dif_crop_resize_multi: bad sizes");
+  if (n == 0) return 0;
+  if (!frames_dev || !boxes_ltrb_dev || !out_dev) return set_error("dif_crop_resize_multi: null pointer");
+  int64_t blocks = ((int64_t)n * k * size * size + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(crop_resize_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, frames_dev, n * k, h, w,
+                     boxes_ltrb_dev, margin, out_dev, size, size, k, valid_dev);
   DIF_HIP(hipGetLastError());
   return 0;
 }

@@ -102,7 +102,7 @@ int Net::out_tensor(int H, int W, int C) {
   return v;
 }
 
-int Net::pool(const std::string& name, int x, int k, int stride, int pad, int mode, int zero_pad) {
+int Net::pool(const std::string& name, int x, int k, int stride, int pad, int mode, int zero_pad, bool ceil_mode) {
   const TensorDesc td = tensors[x];
   Op p;
   p.kind = OP_MAXPOOL;
@@ -114,7 +114,9 @@ int Net::pool(const std::string& name, int x, int k, int stride, int pad, int mo
   p.zero_pad = zero_pad;
   p.pool_mode = mode;
   p.Cin = p.Cout = td.C;
-  p.y = out_tensor((td.H + 2 * pad - k) / stride + 1, (td.W + 2 * pad - k) / stride + 1, td.C);
+  // ceil_mode (Caffe's pooling, MTCNN): the last window may hang over the bottom / right edge; the kernel skips taps outside
+  const int rnd = ceil_mode ? stride - 1 : 0;
+  p.y = out_tensor((td.H + 2 * pad - k + rnd) / stride + 1, (td.W + 2 * pad - k + rnd) / stride + 1, td.C);
   ops.push_back(p);
   return p.y;
 }
@@ -797,8 +799,71 @@ int Net::build_yolov3() {
   return 0;
 }
 
+// ----------------------------------------------------------------------------- MTCNN (BASELINE configs[4] as worded)
+// NOT IN THE REFERENCE (config.py:37 and detector/run.py:124 only mention it in comments; the detector it ships is
+// YOLOv3-face, above).  Layer tables of the public MTCNN (Zhang et al. 2016, "Joint Face Detection and Alignment using
+// Multi-task Cascaded Convolutional Networks"), restated from the published definition: every convolution VALID with bias
+// and PReLU, Caffe max-pooling (ceil mode).
+//   P-Net: conv3x3(10) - pool2/2 - conv3x3(16) - conv3x3(32) - {conv1x1(2) face / not-face logits, conv1x1(4) box regression}
+//   R-Net (24 x 24): conv3x3(28) - pool3/2 - conv3x3(48) - pool3/2 - conv2x2(64) - fc(128) - {fc(2), fc(4)}
+//   O-Net (48 x 48): conv3x3(32) - pool3/2 - conv3x3(64) - pool3/2 - conv3x3(64) - pool2/2 - conv2x2(128) - fc(256) - {fc(2), fc(4), fc(10)}
+// Here: the sibling heads of a network are ONE layer whose filters are their concatenation (`head`: [logits 2 | box 4 |
+// (landmarks 10) | zero filters up to a multiple of 4]) -- the same products, one launch; P-Net's 10 first-layer filters are
+// held as 12 (two zero filters, whose outputs the next layer's zero weights ignore: channel counts stay multiples of 4); a
+// fully connected layer over an h x w x c map is the h x w VALID convolution with kernel [h, w, c, out] (HWC flattening).
+// The output is the head's map: [H', W', 8] for P-Net, [1, 1, 8] for R-Net, [1, 1, 16] for O-Net.
+int Net::build_mtcnn(int stage) {
+  const BNRef none;
+  if (stage == 1 && (in_h < 12 || in_w < 12)) return set_error("mtcnn_pnet input must be at least 12x12 (got %dx%d)", in_h, in_w);
+  if (stage == 2 && (in_h != 24 || in_w != 24)) return set_error("mtcnn_rnet input is 24x24");
+  if (stage == 3 && (in_h != 48 || in_w != 48)) return set_error("mtcnn_onet input is 48x48");
+  input_tensor = T(in_h, in_w, 4);
+  {
+    Op in;
+    in.kind = OP_INPUT;
+    in.name = "input";
+    in.y = input_tensor;
+    ops.push_back(in);
+  }
+  auto cp = [&](const std::string& nm, int x, int k, int cout, bool prelu) {
+    const int al = prelu ? P(nm + "_prelu/alpha", {cout}) : -1;
+    return conv(nm, x, k, k, 1, 0, cout, true, none, prelu ? ACT_PRELU : ACT_NONE, al, -1, 1, true, none, ACT_NONE, nullptr);
+  };
+  int x = input_tensor;
+  if (stage == 1) {
+    x = cp("conv1", x, 3, 12, true);
+    x = pool("pool1", x, 2, 2, 0, POOL_MAX, 0, true);
+    x = cp("conv2", x, 3, 16, true);
+    x = cp("conv3", x, 3, 32, true);
+    x = cp("head", x, 1, 8, false);
+  } else if (stage == 2) {
+    x = cp("conv1", x, 3, 28, true);
+    x = pool("pool1", x, 3, 2, 0, POOL_MAX, 0, true);
+    x = cp("conv2", x, 3, 48, true);
+    x = pool("pool2", x, 3, 2, 0, POOL_MAX, 0, true);
+    x = cp("conv3", x, 2, 64, true);
+    x = cp("fc1", x, tensors[x].H, 128, true);
+    x = cp("head", x, 1, 8, false);
+  } else {
+    x = cp("conv1", x, 3, 32, true);
+    x = pool("pool1", x, 3, 2, 0, POOL_MAX, 0, true);
+    x = cp("conv2", x, 3, 64, true);
+    x = pool("pool2", x, 3, 2, 0, POOL_MAX, 0, true);
+    x = cp("conv3", x, 3, 64, true);
+    x = pool("pool3", x, 2, 2, 0, POOL_MAX, 0, true);
+    x = cp("conv4", x, 2, 128, true);
+    x = cp("fc1", x, tensors[x].H, 256, true);
+    x = cp("head", x, 1, 16, false);
+  }
+  output_tensor = x;
+  return 0;
+}
+
 int Net::build() {
   if (emd <= 0) return set_error("emd_size must be positive");
+  if (arch == "mtcnn_pnet") return build_mtcnn(1);
+  if (arch == "mtcnn_rnet") return build_mtcnn(2);
+  if (arch == "mtcnn_onet") return build_mtcnn(3);
   if (in_h < 32 || in_w < 32) return set_error("input must be at least 32x32");
   if (arch == "resnet") return build_resnet50v2();
   if (arch == "iresnet50") {
@@ -814,7 +879,7 @@ int Net::build() {
     return build_iresnet(l);
   }
   return set_error("Invalid bottleneck network '%s' (supported: resnet, vgg16, mobilenet, iresnet50, iresnet100, nn4, "
-                   "yolov3)", arch.c_str());
+                   "yolov3, mtcnn_pnet, mtcnn_rnet, mtcnn_onet)", arch.c_str());
 }
 
 double Net::flops_per_image() const {

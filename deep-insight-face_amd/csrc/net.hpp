@@ -176,13 +176,14 @@ struct Net {
   int V(int parent, int H, int W, int C, int coff, int oy, int ox);   // view tensor
   void into(int parent, int coff, int oy = 0, int ox = 0);           // the next conv/pool writes into this view
   int out_tensor(int H, int W, int C);
-  int pool(const std::string& name, int x, int k, int stride, int pad, int mode, int zero_pad);
+  int pool(const std::string& name, int x, int k, int stride, int pad, int mode, int zero_pad, bool ceil_mode = false);
   int pend_parent = -1, pend_coff = 0, pend_oy = 0, pend_ox = 0;
   int root_of(int t) const { return tensors[t].parent >= 0 ? tensors[t].parent : t; }
   int conv(const std::string& name, int x, int KH, int KW, int stride, int pad, int Cout, bool bias,
            const BNRef& bn, int act, int alpha, int res, int res_stride, bool want_y, const BNRef& bn2, int act2,
            int* y2_out, const std::string& wsuffix = "/kernel", bool same_pad_even = false, int pad_br = -1);
   int build_yolov3();
+  int build_mtcnn(int stage);   // 1 P-Net (any input size), 2 R-Net (24 x 24), 3 O-Net (48 x 48)
   int build_resnet50v2();
   void add_input();
   int build_heads(int feat);         // v1 / v2 / v3 head of triplet.py:102-141 on a backbone's feature map

@@ -41,6 +41,11 @@ SIGNATURES = {
     'dif_letterbox': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     'dif_crop_resize': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_int, c_void_p]),
     'dif_area_resize': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
+    'dif_crop_resize_multi': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_int, c_void_p]),
+    'dif_mtcnn_propose': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    'dif_mtcnn_gather': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                 c_int, c_int, c_int, c_void_p]),
+    'dif_mtcnn_rescore': (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'dif_gallery_create': (c_int, [P(c_void_p), c_int]),
     'dif_gallery_destroy': (c_int, [c_void_p]),
     'dif_gallery_set': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),

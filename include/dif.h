@@ -107,6 +107,36 @@ int dif_crop_resize(const uint8_t* frames_dev, int n, int h, int w, const float*
 int dif_area_resize(const uint8_t* images_dev, int n, int h, int w, uint8_t* out_dev, int out_h, int out_w,
                     void* stream);
 
+/* ------------------------------------------------------------------ MTCNN cascade (BASELINE configs[4] as worded)
+ * NOT IN THE REFERENCE (config.py:37, detector/run.py:124 name it in comments only; the detector it ships is YOLOv3-face,
+ * above).  The three networks are dif_net archs "mtcnn_pnet" (any input >= 12 x 12; output map [H', W', 8] = logits 2 |
+ * box regression 4 | 0 0), "mtcnn_rnet" (24 x 24 -> [8]) and "mtcnn_onet" (48 x 48 -> [16] = logits 2 | box 4 | landmarks
+ * 10); inputs are (x - 127.5) / 128 (dif_net_set_input_transform).  The entry points below are the arithmetic between
+ * them, on static shapes -- a fixed number of slots per frame and stage, an empty slot has score -1 -- so that a batch of
+ * frames runs the whole cascade without a host round trip; dif_nms (above) does every suppression (scores >= 0 take part).
+ * The calling convention kept from the reference is detector/run.py:120-173 (deep_insight_face.detector.mtcnn).
+ * dif_mtcnn_propose: head map [n][gh][gw][ld] of P-Net at pyramid scale `scale` -> one proposal per cell:
+ *   boxes_dev [n][gh*gw][4] = trunc((2 g + 1) / scale), trunc((2 g + 12) / scale) as (x1, y1, x2, y2) in frame pixels,
+ *   scores_dev [n][gh*gw] = P(face) = softmax(logits)[1], or -1 below `threshold`.
+ * dif_mtcnn_gather: slot (f, dst_offset + j) of the destination arrays ([n][n_dst] slots) <- source slot (f, keep[f][j])
+ *   ([n][n_src] slots; src_reg rows are src_reg_ld floats apart -- the P-Net map itself serves, offset to its box
+ *   channels), keep < 0 -> an empty slot; calibrate != 0: the box is regressed (x += reg * (side + 1)), squared around its
+ *   centre and truncated first.  dst_reg_dev may be NULL.
+ * dif_mtcnn_rescore: network outputs out_dev [slots][ld] -> scores (P(face) where the slot was alive and passes
+ *   `threshold`, else -1) and reg_dev [slots][4]; plain_regression != 0 also regresses boxes_dev in place without
+ *   squaring (the cascade's last step).
+ * dif_crop_resize_multi: k boxes per frame, boxes [n][k][4] (left, top, right, bottom), valid_dev [n][k] (may be NULL;
+ *   negative = empty slot -> black crop) -> out_dev [n*k][size][size][3]; arithmetic of dif_crop_resize. */
+int dif_mtcnn_propose(const float* head_dev, int n, int gh, int gw, int ld, float scale, float threshold, float* boxes_dev,
+                      float* scores_dev, void* stream);
+int dif_mtcnn_gather(const int32_t* keep_dev, int n, int k, const float* src_boxes_dev, const float* src_scores_dev,
+                     const float* src_reg_dev, int src_reg_ld, int n_src, float* dst_boxes_dev, float* dst_scores_dev,
+                     float* dst_reg_dev, int n_dst, int dst_offset, int calibrate, void* stream);
+int dif_mtcnn_rescore(const float* out_dev, int slots, int ld, float threshold, float* scores_dev, float* reg_dev,
+                      float* boxes_dev, int plain_regression, void* stream);
+int dif_crop_resize_multi(const uint8_t* frames_dev, int n, int h, int w, const float* boxes_ltrb_dev, const float* valid_dev,
+                          int k, float margin, uint8_t* out_dev, int size, void* stream);
+
 /* ------------------------------------------------------------------ gallery + 1:N match
  * The reference has no 1:N entry point; the semantics are utility.distance broadcast
  * over gallery rows + np.argmin (first minimum).  Housed Python-side under
@@ -173,7 +203,8 @@ int dif_match_merge_packed(const void* packed_dev, int R, int n, int64_t* idx_ou
  * Stands behind the Keras model object of the reference:
  *   bottleneck_network(net, emd_size, input_shape)(default_model_ver)   networks/triplet.py:73-85
  *   emd_model.predict_on_batch(x[N,H,W,3]) -> [N,emd]                    predictions.py:96,156; evaluation/evals.py:56
- * arch: "resnet" (keras ResNet50V2, triplet.py:90-91), "iresnet50", "iresnet100"
+ * arch: "resnet" (keras ResNet50V2, triplet.py:90-91), "iresnet50", "iresnet100" (also "vgg16", "mobilenet", "nn4",
+ *       "yolov3", "mtcnn_pnet" / "mtcnn_rnet" / "mtcnn_onet")
  * head: "v1" (triplet.py:102-117), "v2" (GDC + L2-norm, triplet.py:119-141),
  *       "v3" (bare backbone, triplet.py:143-146); ignored for iresnet*. */
 int dif_net_create(dif_net** out, const char* arch, const char* head, int emd_size, int in_h, int in_w);

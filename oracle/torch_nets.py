@@ -248,3 +248,29 @@ def yolov3(x_nhwc, p):
         b, y26 = head(torch.cat([F.interpolate(cbl(b, 1, 1), scale_factor=2, mode='nearest'), routes[512]], 1))
         b, y52 = head(torch.cat([F.interpolate(cbl(b, 1, 1), scale_factor=2, mode='nearest'), routes[256]], 1))
     return [np.ascontiguousarray(t.permute(0, 2, 3, 1).numpy()) for t in (y13, y26, y52)]
+
+
+# ---------------------------------------------------------------------------- MTCNN (oracle/mtcnn.py; not in the reference)
+def mtcnn(x_nhwc, p, stage):
+    """stage 'pnet' / 'rnet' / 'onet'; x already normalised; -> head output, NHWC map for P-Net, [N, C] otherwise."""
+    x = torch.from_numpy(x_nhwc).permute(0, 3, 1, 2).contiguous()
+
+    def cp(t, name, prelu=True):
+        t = _conv(t, p, name)
+        return F.prelu(t, _t(p, name + '_prelu/alpha')) if prelu else t
+
+    with torch.no_grad():
+        if stage == 'pnet':
+            y = F.max_pool2d(cp(x, 'conv1'), 2, 2, ceil_mode=True)
+            y = cp(cp(cp(y, 'conv2'), 'conv3'), 'head', False)
+            return y.permute(0, 2, 3, 1).contiguous().numpy()
+        if stage == 'rnet':
+            y = F.max_pool2d(cp(x, 'conv1'), 3, 2, ceil_mode=True)
+            y = F.max_pool2d(cp(y, 'conv2'), 3, 2, ceil_mode=True)
+            y = cp(cp(cp(y, 'conv3'), 'fc1'), 'head', False)
+            return y.flatten(1).numpy()
+        y = F.max_pool2d(cp(x, 'conv1'), 3, 2, ceil_mode=True)
+        y = F.max_pool2d(cp(y, 'conv2'), 3, 2, ceil_mode=True)
+        y = F.max_pool2d(cp(y, 'conv3'), 2, 2, ceil_mode=True)
+        y = cp(cp(cp(y, 'conv4'), 'fc1'), 'head', False)
+        return y.flatten(1).numpy()
