@@ -75,26 +75,30 @@ __device__ __forceinline__ float box_iou(const float* p, const float* q) {
 
 // One block per (image, class).  Greedy: pick the best remaining score (ties: lower index, the
 // order of tf.image.non_max_suppression), keep it, drop everything with IoU > threshold.
-__global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
-                                                  int ntot, int C, int max_boxes, float score_thr, float iou_thr,
-                                                  uint8_t* __restrict__ alive, int* __restrict__ keep_idx,
-                                                  int* __restrict__ keep_n) {
-  __shared__ float s_score[4];
-  __shared__ int s_idx[4];
+// NT threads per block: 256 for YOLOv3-face's 10 647 boxes per image; 1024 for MTCNN's dense P-Net grids (26 k cells per frame
+// at the first pyramid scale, up to 64 picks: the scans were 39 % of that workload's GPU time at 256 threads)
+template <int NT>
+__global__ __launch_bounds__(NT) void nms_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                 int ntot, int C, int max_boxes, float score_thr, float iou_thr,
+                                                 uint8_t* __restrict__ alive, int* __restrict__ keep_idx,
+                                                 int* __restrict__ keep_n) {
+  constexpr int NW = NT / 64;
+  __shared__ float s_score[NW];
+  __shared__ int s_idx[NW];
   __shared__ int s_pick;
   const int n = blockIdx.x, c = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* bx = boxes + (int64_t)n * ntot * 4;
   const float* sc = scores + (int64_t)n * ntot * C + c;
   uint8_t* al = alive + ((int64_t)n * C + c) * ntot;
   int* out = keep_idx + ((int64_t)n * C + c) * max_boxes;
-  for (int i = tid; i < ntot; i += 256) al[i] = sc[(int64_t)i * C] >= score_thr ? 1 : 0;   // mask = box_scores >= thr
-  for (int i = tid; i < max_boxes; i += 256) out[i] = -1;
+  for (int i = tid; i < ntot; i += NT) al[i] = sc[(int64_t)i * C] >= score_thr ? 1 : 0;   // mask = box_scores >= thr
+  for (int i = tid; i < max_boxes; i += NT) out[i] = -1;
   __syncthreads();
   int kept = 0;
   while (kept < max_boxes) {
     float best = -__builtin_inff();
     int bi = 0x7fffffff;
-    for (int i = tid; i < ntot; i += 256) {
+    for (int i = tid; i < ntot; i += NT) {
       if (al[i]) {
         const float s = sc[(int64_t)i * C];
         if (s > best || (s == best && i < bi)) {
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ boxe
     if (tid == 0) {
       float b = s_score[0];
       int k = s_idx[0];
-      for (int w = 1; w < 4; ++w)
+      for (int w = 1; w < NW; ++w)
         if (s_score[w] > b || (s_score[w] == b && s_idx[w] < k)) {
           b = s_score[w];
           k = s_idx[w];
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ boxe
     if (tid == 0) out[kept] = pick;
     ++kept;
     float pb[4] = {bx[(int64_t)pick * 4], bx[(int64_t)pick * 4 + 1], bx[(int64_t)pick * 4 + 2], bx[(int64_t)pick * 4 + 3]};
-    for (int i = tid; i < ntot; i += 256)
+    for (int i = tid; i < ntot; i += NT)
       if (al[i] && (i == pick || box_iou(bx + (int64_t)i * 4, pb) > iou_thr)) al[i] = 0;
     __syncthreads();
   }
@@ -191,9 +195,12 @@ int dif_nms(const float* boxes_dev, const float* scores_dev, int n_images, int n
   if (n_images == 0) return 0;
   if (!boxes_dev || !scores_dev || !alive_ws_dev || !keep_idx_dev || !keep_count_dev)
     return set_error("dif_nms: null pointer");
-  hipLaunchKernelGGL(nms_kernel, dim3(n_images, n_classes), dim3(256), 0, (hipStream_t)stream, boxes_dev, scores_dev,
-                     n_boxes, n_classes, max_boxes, score_threshold, iou_threshold, alive_ws_dev, keep_idx_dev,
-                     keep_count_dev);
+  if (n_boxes > 12288)
+    hipLaunchKernelGGL(nms_kernel<1024>, dim3(n_images, n_classes), dim3(1024), 0, (hipStream_t)stream, boxes_dev, scores_dev,
+                       n_boxes, n_classes, max_boxes, score_threshold, iou_threshold, alive_ws_dev, keep_idx_dev, keep_count_dev);
+  else
+    hipLaunchKernelGGL(nms_kernel<256>, dim3(n_images, n_classes), dim3(256), 0, (hipStream_t)stream, boxes_dev, scores_dev,
+                       n_boxes, n_classes, max_boxes, score_threshold, iou_threshold, alive_ws_dev, keep_idx_dev, keep_count_dev);
   DIF_HIP(hipGetLastError());
   return 0;
 }

@@ -49,7 +49,7 @@ def main():
     cp('ks_default_1lane/p_kernel_stats.csv', R + '_default_1lane_kernel_stats.csv')
     cp('ks_default_1lane.json', R + '_default_1lane_bench_profiled.json')
     cp('ks_r50_1lane/p_kernel_stats.csv', R + '_r50_1lane_kernel_stats.csv')
-    for w in ('default', 'default_1lane', 'r100', 'r50', 'r50_1lane', 'r100_arc', 'r100_1m_bf16x3', 'r100_1m_bf16x2', 'frames', 'default_fc'):
+    for w in ('default', 'default_1lane', 'r100', 'r50', 'r50_1lane', 'r100_arc', 'r100_1m_bf16x3', 'r100_1m_bf16x2', 'frames', 'frames_mtcnn', 'default_fc'):
         cp('bench_%s.json' % w, '%s_%s_bench.json' % (R, w))
     for src, dst in (('layers_r100.txt', 'r100_b256_layers.txt'), ('layers_r50.txt', 'r50_b256_layers.txt'),
                      ('layers_r100_bf16x2.txt', 'r100_b256_bf16x2_layers.txt'), ('layers_yolov3.txt', 'yolov3_b64_layers.txt'),
@@ -125,7 +125,7 @@ def main():
     lines.append('r50 (configs[1]), ONE lane: %d conv launches per forward, %.3f ms of conv kernels per forward (stats) vs HIP-event '
                  'forward %.3f ms (un-profiled run), frac %.4f' % (round(calls / fw50), ms / fw50, r50['roofline']['forward_ms_hip_events'],
                                                                   r50['roofline']['frac']))
-    for w in ('r100', 'r50', 'r100_arc', 'r100_1m_bf16x3', 'r100_1m_bf16x2', 'frames', 'default_fc'):
+    for w in ('r100', 'r50', 'r100_arc', 'r100_1m_bf16x3', 'r100_1m_bf16x2', 'frames', 'frames_mtcnn', 'default_fc'):
         b = jl(os.path.join(OUT, 'bench_%s.json' % w))
         lines.append('%-16s %8.0f %s  step %.2f ms  phases %s  frac(f32 peak) %.4f'
                      % (w, b['value'], b['unit'], b['ms_per_step'], json.dumps(b['phases_ms']), b['roofline']['frac']))

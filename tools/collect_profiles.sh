@@ -32,6 +32,7 @@ python3 bench.py --workload r100_1m_bf16x3 --no-cpu-baseline > $O/bench_r100_1m_
 python3 bench.py --workload r100_1m_bf16x2 --no-cpu-baseline > $O/bench_r100_1m_bf16x2.json 2>/dev/null &&
 python3 bench.py --force-collectives --no-cpu-baseline --no-throughput-mode > $O/bench_default_fc.json 2>/dev/null &&
 python3 bench.py --workload frames --steps 3 --warmup 1 > $O/bench_frames.json 2>/dev/null &&
+python3 bench.py --workload frames_mtcnn --steps 5 --warmup 2 > $O/bench_frames_mtcnn.json 2>/dev/null &&
 # 5. per-layer tables, latency
 python3 tools/layer_profile.py iresnet100 256 > $O/layers_r100.txt 2>&1 &&
 python3 tools/layer_profile.py resnet 256 > $O/layers_r50.txt 2>&1 &&
