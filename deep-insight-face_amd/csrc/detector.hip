@@ -7,6 +7,7 @@
 #include "dif_internal.hpp"
 
 namespace dif {
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct YoloLayer {
   const float* feats;   // [N][gh][gw][na*(5+C)]
@@ -144,6 +145,97 @@ __global__ __launch_bounds__(NT) void nms_kernel(const float* __restrict__ boxes
   if (tid == 0) keep_n[n * C + c] = kept;
 }
 
+// The same greedy suppression for ONE class and up to NT * IPT boxes per image, with every box and score held in REGISTERS:
+// a thread owns boxes tid, tid + NT, ... (IPT of them); a pick is a local arg-max over its registers, a block reduction,
+// and a suppression pass over its registers -- no memory traffic inside the loop.  nms_kernel scans the alive bytes, the
+// scores and the boxes in global memory twice per pick: 1.4 ms per launch on MTCNN's dense 26 k-cell P-Net grid, a
+// quarter of that workload's GPU time.  Same picks in the same order (highest score, ties by lower index; IoU > threshold
+// suppresses), so the same keep lists bit for bit.
+// SLDS: the scores live in LDS instead (4 IPT NT bytes): 26 boxes + 26 scores per thread do not fit the 128 registers a
+// 1024-thread block leaves a lane
+template <int NT, int IPT, bool SLDS>
+__global__ __launch_bounds__(NT) void nms_reg_kernel(const float* __restrict__ boxes, const float* __restrict__ scores, int ntot,
+                                                     int max_boxes, float score_thr, float iou_thr, int* __restrict__ keep_idx,
+                                                     int* __restrict__ keep_n) {
+  constexpr int NW = NT / 64;
+  __shared__ float s_score[NW];
+  __shared__ int s_idx[NW];
+  __shared__ float s_box[4];
+  __shared__ int s_pick;
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* bx = boxes + (int64_t)n * ntot * 4;
+  const float* sc = scores + (int64_t)n * ntot;
+  int* out = keep_idx + (int64_t)n * max_boxes;
+  extern __shared__ float s_lds[];                          // SLDS: [IPT][NT]
+  float b[IPT][4], s_reg[SLDS ? 1 : IPT];
+  auto S = [&](int j) -> float& { if constexpr (SLDS) return s_lds[j * NT + tid]; else return s_reg[j]; };
+#pragma unroll
+  for (int j = 0; j < IPT; ++j) {
+    const int i = tid + NT * j;
+    S(j) = -__builtin_inff();
+    b[j][0] = b[j][1] = b[j][2] = b[j][3] = 0.f;
+    if (i < ntot) {
+      const float v = sc[i];
+      if (v >= score_thr) S(j) = v;                        // NaN scores never take part, as in nms_kernel
+      const f32x4 q = *reinterpret_cast<const f32x4*>(bx + (int64_t)i * 4);
+      b[j][0] = q[0];
+      b[j][1] = q[1];
+      b[j][2] = q[2];
+      b[j][3] = q[3];
+    }
+  }
+  for (int i = tid; i < max_boxes; i += NT) out[i] = -1;
+  int kept = 0;
+  while (kept < max_boxes) {
+    float best = -__builtin_inff();
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < IPT; ++j)                            // ascending index: the first maximum is the lowest index
+      if (S(j) > best) {
+        best = S(j);
+        bi = tid + NT * j;
+      }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float os = __shfl_xor(best, o);
+      const int oi = __shfl_xor(bi, o);
+      if (os > best || (os == best && oi < bi)) {
+        best = os;
+        bi = oi;
+      }
+    }
+    if (lane == 0) {
+      s_score[wave] = best;
+      s_idx[wave] = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float bb = s_score[0];
+      int k = s_idx[0];
+      for (int w = 1; w < NW; ++w)
+        if (s_score[w] > bb || (s_score[w] == bb && s_idx[w] < k)) {
+          bb = s_score[w];
+          k = s_idx[w];
+        }
+      s_pick = k;
+      if (k != 0x7fffffff) {
+        out[kept] = k;
+        for (int e = 0; e < 4; ++e) s_box[e] = bx[(int64_t)k * 4 + e];
+      }
+    }
+    __syncthreads();
+    const int pick = s_pick;
+    if (pick == 0x7fffffff) break;                         // nothing left
+    ++kept;
+    const float pb[4] = {s_box[0], s_box[1], s_box[2], s_box[3]};
+#pragma unroll
+    for (int j = 0; j < IPT; ++j)
+      if (S(j) > -__builtin_inff() && (tid + NT * j == pick || box_iou(b[j], pb) > iou_thr)) S(j) = -__builtin_inff();
+    __syncthreads();                                       // s_pick / s_box are rewritten by the next round
+  }
+  if (tid == 0) keep_n[n] = kept;
+}
+
 }  // namespace dif
 
 using namespace dif;
@@ -195,6 +287,27 @@ int dif_nms(const float* boxes_dev, const float* scores_dev, int n_images, int n
   if (n_images == 0) return 0;
   if (!boxes_dev || !scores_dev || !alive_ws_dev || !keep_idx_dev || !keep_count_dev)
     return set_error("dif_nms: null pointer");
+  // one class and few enough boxes for the register form (MTCNN's grids and slot lists, YOLOv3-face's 10 647 boxes): the
+  // workspace is not used
+  if (n_classes == 1 && n_boxes <= 1024 * 26) {
+    if (n_boxes <= 1024 * 11)
+      hipLaunchKernelGGL((nms_reg_kernel<1024, 11, false>), dim3(n_images), dim3(1024), 0, (hipStream_t)stream, boxes_dev, scores_dev,
+                         n_boxes, max_boxes, score_threshold, iou_threshold, keep_idx_dev, keep_count_dev);
+    else {
+      static bool attr_set[64];
+      int dev = 0;
+      DIF_HIP(hipGetDevice(&dev));
+      if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        DIF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nms_reg_kernel<1024, 26, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 26 * 1024 * 4));
+        attr_set[dev] = true;
+      }
+      hipLaunchKernelGGL((nms_reg_kernel<1024, 26, true>), dim3(n_images), dim3(1024), 26 * 1024 * 4, (hipStream_t)stream, boxes_dev,
+                         scores_dev, n_boxes, max_boxes, score_threshold, iou_threshold, keep_idx_dev, keep_count_dev);
+    }
+    DIF_HIP(hipGetLastError());
+    return 0;
+  }
   if (n_boxes > 12288)
     hipLaunchKernelGGL(nms_kernel<1024>, dim3(n_images, n_classes), dim3(1024), 0, (hipStream_t)stream, boxes_dev, scores_dev,
                        n_boxes, n_classes, max_boxes, score_threshold, iou_threshold, alive_ws_dev, keep_idx_dev, keep_count_dev);
