@@ -640,3 +640,26 @@ def test_one_image_kernel_equals_other_paths(cuda, arch, head, emd, shape, n):
         scale = max(float(tb.abs().max()), 1.0)
         assert float((ta - tb).abs().max()) <= (2e-5 if arch == 'yolov3' else 4e-6) * scale, arch
     m.close()
+
+
+def test_small_batches_on_a_large_max_batch_model(cuda):
+    """bench.py's `latency` block (and any serving process) embeds 1 / 8 / 32 images on a model finalized for hundreds: the
+    small-batch kernels are chosen from the batch at hand, not from max_batch, and the result does not depend on max_batch --
+    bit-identical to a model finalized for exactly that batch, and within 1e-5 of the oracle."""
+    u8 = crops_u8(12, seed=9)
+    big, p = build('iresnet50', 'v2', 512, max_batch=192)
+    big.set_input_transform(scale=1 / 255.)
+    want = nets.embed(scaled(u8), p, 'iresnet50', 512, 'v2')
+    for n in (1, 8, 12):
+        small, _ = build('iresnet50', 'v2', 512, max_batch=n)
+        small.set_input_transform(scale=1 / 255.)
+        a = big.predict_on_batch(u8[:n])
+        b = small.predict_on_batch(u8[:n])
+        assert np.array_equal(a, b), n
+        assert cosine_gap(a, want[:n]).max() < TOL
+        kinds = {k.split('<')[0] for _, k, _, _ in big.profile(torch.from_numpy(u8[:n]).cuda())}
+        assert ('conv_mt_kernel' in kinds) if n == 1 else ('conv_sk_kernel' in kinds or 'conv_skp_kernel' in kinds), (n, kinds)
+        small.close()
+    full = big.predict_on_batch(crops_u8(192, seed=10))                    # the large-batch kernels still run on it afterwards
+    assert np.all(np.isfinite(full)) and full.shape == (192, 512)
+    big.close()
