@@ -374,7 +374,7 @@ def main():
     ap.add_argument('--gallery', type=int, default=0, help='total gallery rows override')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-throughput-mode', action='store_true', help='skip the extra split-bf16 forward timing')
-    ap.add_argument('--no-latency', action='store_true', help='skip the small-batch (1 / 8 / 32) forward latency block')
+    ap.add_argument('--no-latency', action='store_true', help='skip the small-batch (1 / 8 / 12 / 32) forward latency block')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='gloo = rehearsal of the N>1 path on a box with fewer GPUs than ranks (collectives staged '
                          'through the host, ranks share devices); never used for reported numbers')
@@ -584,7 +584,7 @@ def main():
     latency = None
     if pipe is None and compute == 'f32' and not args.no_latency:
         latency = {}
-        for lb in (1, 8, 32):
+        for lb in (1, 8, 12, 32):                               # 12: scripts/insight_face.py:112, the reference's evaluation batch
             if lb > batch:
                 continue
             xs = crops[:lb]
