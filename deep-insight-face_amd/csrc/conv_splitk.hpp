@@ -287,6 +287,7 @@ __device__ __forceinline__ void gemm_mainloop_deep(const ALoader& al, const BLoa
 }
 
 constexpr int SK_DEPTH = 5;             // K-steps in flight per block: 5 x (8 KB + 8 KB) = 80 VGPRs of operands
+constexpr int SK_DEPTH_PRE = 3;         // ... with pre-activation constants riding along (8 more VGPRs per K-step): five spilled 12-20 registers
 
 template <class T, bool PRE, int AM>
 __global__ __launch_bounds__(T::NT, 2) void conv_sk_kernel(const ConvArgs a, int S, int tiles_m, int tiles_n) {
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(T::NT, 2) void conv_sk_kernel(const ConvArgs a, int
   const ALoad al(a, m0);
   const BLoad bl(a.w + (int64_t)n0 * a.Kpad, (int64_t)a.Cout - n0, a.Kpad);
   const unsigned long long tr_t1 = a.trace ? __builtin_amdgcn_s_memrealtime() : 0;
-  if (ke > kb) gemm_mainloop_deep<T, SK_DEPTH, ALoad, BLoad, SkPre<PRE>>(al, bl, kb, ke, smem, acc);
+  if (ke > kb) gemm_mainloop_deep<T, (PRE ? SK_DEPTH_PRE : SK_DEPTH), ALoad, BLoad, SkPre<PRE>>(al, bl, kb, ke, smem, acc);
   const unsigned long long tr_t2 = a.trace ? __builtin_amdgcn_s_memrealtime() : 0;
   float* slab = a.sk_slab + ((int64_t)(mt * tiles_n + nt) * S + s) * (T::BM * T::BN);
 #pragma unroll
