@@ -2450,7 +2450,10 @@ static int mt_plan(const ConvArgs& a) {
   if ((int64_t)a.N * a.H * a.W * a.Cin * 4 >= 0x7fffffffLL || (int64_t)16 * a.Kpad * 4 >= 0x7fffffffLL) return 0;   // 32-bit offsets
   const int64_t tiles = ((a.M + 15) / 16) * (int64_t)((a.Cout + 15) / 16);
   const int64_t traffic = tiles * 32 * (int64_t)a.Kpad * 4;          // L2 -> CU bytes: no operand is reused inside a tile
-  if (tiles > 2 * (int64_t)num_cus() || traffic > (96ll << 20)) return 0;        // (the 784 tiles of a 56 x 56 x 64 layer: split-K is faster)
+  // (the 784 tiles of a 56 x 56 x 64 3x3 layer: split-K is faster; the 784 of ResNet-50V2's 28 x 28 stage's 1x1 layers, K = 64:
+  // this kernel is, 0.460 -> 0.455 ms per forward -- r05_ablation item 11)
+  const int64_t tile_cap = (pw1 && a.Kpad <= 256 ? 4 : 2) * (int64_t)num_cus();
+  if (tiles > tile_cap || traffic > (96ll << 20)) return 0;
   const int nch = a.Kpad / 16;
   const bool pre = a.pre_scale != nullptr;
   int nw = nch <= 4 * mt_round(4, pre) ? 4 : 8;                      // a wave's run in one round of loads where eight waves allow it
