@@ -532,10 +532,150 @@ __global__ __launch_bounds__(128 * KSPLIT) void gdc_tail_kernel(const float* __r
   }
 }
 
+// One or two images (round 5, late): the single block above streams the two 1 MB weight matrices through ONE CU, ~9 us each
+// at what a CU draws from L2.  Here the two matrix-vector products are spread over E / 32 blocks each -- a block owns 32
+// adjacent outputs (128-byte weight rows, 64 KB of a matrix) --, in two launches: the second needs ALL of the first's outputs,
+// and the kernel boundary is the cheap way to hand a vector from every block to every block (1.5 us; a spinning grid barrier
+// costs more and can hang).  The normalisation needs all of the second product's outputs: its blocks publish their 32 values
+// write-through (sc1), drain, draw a ticket; the block that draws the last one normalises and writes the rows (nobody waits).
+//   gdc_tail_a_kernel  depthwise + BN (every block for itself: 3 x 32 KB from L2) -> its 32 columns of the 1x1 convolution
+//   gdc_tail_b_kernel  its 32 columns of the dense layer -> ws; last block: l2-normalise
+// ws: [2][1024] 1x1 outputs, [2][1024] dense outputs, the ticket (zero between launches: its last taker clears it).
+// Summation order: 32 K slices of K / 32 consecutive terms each, added in slice order -- fixed, not the single block's.
+constexpr int GT_JB = 32;              // outputs per block
+__device__ __forceinline__ void gt_gemv_slice(const float* __restrict__ W, int K, int E, int j0, const float* v0, const float* v1,
+                                              float (*part)[2][GT_JB], float* out0, float* out1) {
+  // thread = (K slice ks = tid >> 3, four adjacent outputs jq = tid & 7); 256 threads
+  const int tid = threadIdx.x, ks = tid >> 3, jq = tid & 7;
+  const int kn = K / 32, k0 = ks * kn;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 16
+  for (int k = k0; k < k0 + kn; ++k) {
+    const f32x4 w = *reinterpret_cast<const f32x4*>(W + (int64_t)k * E + j0 + 4 * jq);
+    const float u0 = v0[k], u1 = v1[k];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      s0[q] = fmaf(u0, w[q], s0[q]);
+      s1[q] = fmaf(u1, w[q], s1[q]);
+    }
+  }
+  *reinterpret_cast<f32x4*>(&part[ks][0][4 * jq]) = s0;
+  *reinterpret_cast<f32x4*>(&part[ks][1][4 * jq]) = s1;
+  __syncthreads();
+  if (tid < 2 * GT_JB) {
+    const int img = tid >> 5, j = tid & 31;
+    float t = part[0][img][j];
+#pragma unroll
+    for (int q = 1; q < 32; ++q) t += part[q][img][j];
+    (img ? out1 : out0)[j] = t;
+  }
+}
+
+__global__ __launch_bounds__(256) void gdc_tail_a_kernel(const float* __restrict__ x, const float* __restrict__ wdw,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         const float* __restrict__ wpw, float* __restrict__ ws, int N, int HW, int E) {
+  constexpr int C = 512;
+  __shared__ float a[2][C];
+  __shared__ float part[32][2][GT_JB];
+  const int tid = threadIdx.x;
+  const float* x0 = x;
+  const float* x1 = x + (N > 1 ? (int64_t)HW * C : 0);
+  for (int c = tid; c < C; c += 256) {
+    float s0 = 0.f, s1 = 0.f;
+    for (int p = 0; p < HW; ++p) {
+      const float w = wdw[p * C + c];
+      s0 = fmaf(x0[p * C + c], w, s0);
+      s1 = fmaf(x1[p * C + c], w, s1);
+    }
+    const float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
+    a[0][c] = fmaf(s0, sc, sh);
+    a[1][c] = fmaf(s1, sc, sh);
+  }
+  __syncthreads();
+  const int j0 = blockIdx.x * GT_JB;
+  gt_gemv_slice(wpw, C, E, j0, a[0], a[1], part, ws + j0, ws + 1024 + j0);
+}
+
+__global__ __launch_bounds__(256) void gdc_tail_b_kernel(const float* __restrict__ wd, float* __restrict__ ws,
+                                                         float* __restrict__ y, int N, int E, float eps) {
+  __shared__ float b[2][1024];
+  __shared__ float part[32][2][GT_JB];
+  __shared__ float o[2][GT_JB];
+  __shared__ float red[2][4];
+  __shared__ int s_last;
+  const int tid = threadIdx.x;
+  for (int j = tid; j < E; j += 256) {
+    b[0][j] = ws[j];
+    b[1][j] = ws[1024 + j];
+  }
+  __syncthreads();
+  const int j0 = blockIdx.x * GT_JB;
+  gt_gemv_slice(wd, E, E, j0, b[0], b[1], part, o[0], o[1]);
+  // publish: write-through stores, drained, then one ticket per block (MI355X_MICROARCH.md, visibility: the counter form)
+  float* wo = ws + 2048;
+  unsigned* ticket = reinterpret_cast<unsigned*>(ws + 4096);
+  if (tid < 2 * GT_JB) {
+    const int img = tid >> 5, j = tid & 31;
+    __hip_atomic_store(wo + img * 1024 + j0 + j, o[img][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = old == gridDim.x - 1;
+    if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  // the last block: every output of both images (sc1 loads: the other blocks' stores went through to memory)
+  constexpr int QN = 4;                                      // E <= 1024
+  float v0[QN], v1[QN], ss0 = 0.f, ss1 = 0.f;
+#pragma unroll
+  for (int q = 0; q < QN; ++q) {
+    const int j = tid + 256 * q;
+    v0[q] = v1[q] = 0.f;
+    if (j < E) {
+      v0[q] = __hip_atomic_load(wo + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v1[q] = __hip_atomic_load(wo + 1024 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    ss0 = fmaf(v0[q], v0[q], ss0);
+    ss1 = fmaf(v1[q], v1[q], ss1);
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    ss0 += __shfl_xor(ss0, d);
+    ss1 += __shfl_xor(ss1, d);
+  }
+  if ((tid & 63) == 0) {
+    red[0][tid >> 6] = ss0;
+    red[1][tid >> 6] = ss1;
+  }
+  __syncthreads();
+  const float t0 = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+  const float t1 = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+  const float inv0 = 1.f / sqrtf(fmaxf(t0, eps)), inv1 = 1.f / sqrtf(fmaxf(t1, eps));
+#pragma unroll
+  for (int q = 0; q < QN; ++q) {
+    const int j = tid + 256 * q;
+    if (j < E) {
+      y[j] = v0[q] * inv0;
+      if (N > 1) y[E + j] = v1[q] * inv1;
+    }
+  }
+}
+
 int gdc_tail_run(const float* x, const float* w_dw, const float* scale, const float* shift, const float* w_pw,
-                 const float* w_dense, float* y, int N, int HW, int E, float eps, hipStream_t st) {
+                 const float* w_dense, float* y, int N, int HW, int E, float eps, float* ws, hipStream_t st) {
   if (N == 0) return 0;
   if (E > 1024 || E % 8 != 0) return set_error("gdc_tail: emd %d must be a multiple of 8, at most 1024", E);
+  if (N <= 2 && ws && E % GT_JB == 0) {
+    hipLaunchKernelGGL(gdc_tail_a_kernel, dim3((unsigned)(E / GT_JB)), dim3(256), 0, st, x, w_dw, scale, shift, w_pw, ws, N, HW, E);
+    DIF_HIP(hipGetLastError());
+    hipLaunchKernelGGL(gdc_tail_b_kernel, dim3((unsigned)(E / GT_JB)), dim3(256), 0, st, w_dense, ws, y, N, E, eps);
+    DIF_HIP(hipGetLastError());
+    return 0;
+  }
   if (N <= 2)
     hipLaunchKernelGGL(gdc_tail_kernel<8>, dim3(1), dim3(1024), 0, st, x, w_dw, scale, shift, w_pw, w_dense, y, N, HW, E, eps);
   else

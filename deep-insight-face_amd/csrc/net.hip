@@ -1291,6 +1291,10 @@ int Net::finalize(int mb) {
     L.sk_flag = static_cast<unsigned*>(d);
     DIF_HIP(hipMemset(L.sk_flag, 0, (size_t)sk_max_blocks * sizeof(unsigned)));
     L.sk_epoch = 0;
+    DIF_HIP(hipMalloc(&d, (size_t)GDC_TAIL_WS_FLOATS * sizeof(float)));
+    allocs.push_back(d);
+    L.tail_ws = static_cast<float*>(d);
+    DIF_HIP(hipMemset(L.tail_ws, 0, (size_t)GDC_TAIL_WS_FLOATS * sizeof(float)));
     // persistent-grid size of this lane's stream-K launches.  DIF_SK_LANE_SPLIT=1 gives each lane 1/nl of the
     // chip's resident slots, so the lanes' grids are co-resident instead of queueing behind each other
     L.sk_max_blocks = (lane_split && nl > 1) ? sk_max_blocks / nl : sk_max_blocks;
@@ -1313,7 +1317,7 @@ const char* Net::kernel_name(const Op& op, int n) const {
     case OP_INPUT: return "input_convert_kernel";
     case OP_MAXPOOL: return "maxpool_kernel";
     case OP_DWFULL: return "dwfull_kernel";
-    case OP_GDCTAIL: return "gdc_tail_kernel";
+    case OP_GDCTAIL: return op.ran_kernel && op.ran_kernel[0] ? op.ran_kernel : "gdc_tail_kernel";   // (as the convolutions: what ran last)
     case OP_DWCONV: return "dwconv_kernel";
     case OP_L2NORM: return "l2norm_kernel";
     case OP_LRN: return "lrn_kernel";
@@ -1496,8 +1500,9 @@ int Net::run_op(const Op& op, Lane& L, const void* xin, int n, int layout, int d
     case OP_GDCTAIL: {
       const TensorDesc& xd = tensors[op.x];
       if (gdc_tail_run(ptr(op.x), op.d_w, op.d_scale, op.d_shift, op.d_w_pw, op.d_w_dense, ptr(op.y), n, xd.H * xd.W,
-                       op.Cout, 1e-12f, st))
+                       op.Cout, 1e-12f, L.tail_ws, st))
         return -1;
+      op.ran_kernel = n <= 2 && op.Cout % 32 == 0 ? "gdc_tail_a_kernel+gdc_tail_b_kernel" : "gdc_tail_kernel";
       break;
     }
     case OP_DWFULL: {

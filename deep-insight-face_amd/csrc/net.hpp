@@ -131,6 +131,7 @@ struct Net {
     std::vector<float*> bufs;
     float* sk_slab = nullptr;
     unsigned* sk_flag = nullptr;
+    float* tail_ws = nullptr;         // gdc_tail_run's workspace (one or two images)
     unsigned sk_epoch = 0;
     int sk_max_blocks = 0;
   };

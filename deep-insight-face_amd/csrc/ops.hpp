@@ -167,8 +167,10 @@ int stem_mfma_run(const float* x, const float* w_hwio, const float* scale, const
                   int Ho, int Wo, int KH, int stride, int act, int act2, int y_sub, hipStream_t st);
 // GDC head tail in one launch (networks/triplet.py:129-138): depthwise over the whole map + BN -> 1x1 conv (512 -> E) ->
 // dense (E -> E) -> l2_normalize; x [N][HW][512], w_dw [HW][512], w_pw [512][E], w_dense [E][E], y [N][E]; E <= 1024
+// ws: GDC_TAIL_WS_FLOATS floats, zero when first used, or null -- with it one or two images are spread over E / 32 blocks
+constexpr int GDC_TAIL_WS_FLOATS = 4096 + 16;
 int gdc_tail_run(const float* x, const float* w_dw, const float* scale, const float* shift, const float* w_pw,
-                 const float* w_dense, float* y, int N, int HW, int E, float eps, hipStream_t st);
+                 const float* w_dense, float* y, int N, int HW, int E, float eps, float* ws, hipStream_t st);
 // y = x * rsqrt(max(sum(x^2), eps)) per row
 int l2norm_run(const float* x, float* y, int N, int D, float eps, hipStream_t st);
 

@@ -663,3 +663,26 @@ def test_small_batches_on_a_large_max_batch_model(cuda):
     full = big.predict_on_batch(crops_u8(192, seed=10))                    # the large-batch kernels still run on it afterwards
     assert np.all(np.isfinite(full)) and full.shape == (192, 512)
     big.close()
+
+
+def test_gdc_tail_one_and_two_images(cuda):
+    """The GDC tail (networks/triplet.py:129-138: depthwise over the whole map -> BN -> 1x1 conv -> Dense -> l2_normalize) at
+    one and two images runs as two launches of emd / 32 blocks (gdc_tail_a_kernel / gdc_tail_b_kernel: the second's last
+    block normalises); three and more on the one-launch kernel.  Same products, another fixed summation order: within 1e-5
+    of the oracle either way, rows equal to float32 rounding across the two forms, and repeated calls bit-identical (the
+    ticket the blocks draw is back at zero after every call)."""
+    model, p = build('resnet', 'v2', 512, max_batch=4)
+    x = scaled(crops_u8(3, seed=21))
+    want = nets.embed(x, p, 'resnet', 512, 'v2')
+    three = model.predict_on_batch(x)
+    assert cosine_gap(three, want).max() < TOL
+    for n in (1, 2):
+        got = model.predict_on_batch(x[:n])
+        kernels = [k for _, k, _, _ in model.profile(torch.from_numpy(x[:n]).cuda())]
+        assert 'gdc_tail_a_kernel+gdc_tail_b_kernel' in kernels, kernels
+        assert cosine_gap(got, want[:n]).max() < TOL
+        np.testing.assert_allclose(got, three[:n], atol=2e-6)
+        for _ in range(3):
+            assert np.array_equal(model.predict_on_batch(x[:n]), got)
+    assert 'gdc_tail_kernel' in [k for _, k, _, _ in model.profile(torch.from_numpy(x).cuda())]
+    model.close()
