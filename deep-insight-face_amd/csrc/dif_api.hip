@@ -152,9 +152,9 @@ int dif_gallery_reserve(dif_gallery* h, int64_t capacity, void* stream) {
   // the filter's copy: moved when it fits, otherwise dropped (the next dif_match rebuilds it, or the f32 filter serves)
   if (g.rows1) {
     uint16_t* q = nullptr;
-    if (hipMalloc(&q, c * d * 2) == hipSuccess) {
+    if (hipMalloc(&q, (c + 63) / 64 * 64 * d * 2) == hipSuccess) {   // (whole 64-row tiles: either layout of the first n rows lies inside them)
       if (g.rows1_valid && n) {
-        DIF_HIP(hipMemcpyAsync(q, g.rows1, n * d * 2, hipMemcpyDeviceToDevice, st));
+        DIF_HIP(hipMemcpyAsync(q, g.rows1, (n + 63) / 64 * 64 * d * 2, hipMemcpyDeviceToDevice, st));
         DIF_HIP(hipStreamSynchronize(st));
       }
     } else {
@@ -204,7 +204,7 @@ int dif_gallery_update(dif_gallery* h, const float* rows_dev, int64_t n, int64_t
 int64_t dif_gallery_size(const dif_gallery* h) { return h ? h->g.n : 0; }
 int64_t dif_gallery_capacity(const dif_gallery* h) { return h ? h->g.cap : 0; }
 
-static const char* const kGalleryOptions[] = {"filter", "clamp_nan", "bd", "bd_fill", nullptr};
+static const char* const kGalleryOptions[] = {"filter", "frag", "clamp_nan", "bd", "bd_fill", nullptr};
 
 const char* dif_gallery_option_name(int i) {
   int n = 0;
@@ -230,6 +230,12 @@ int dif_gallery_set_option(dif_gallery* h, const char* key, int value) {
   }
   if (std::string(key) == "bd") {
     h->g.no_bd = value == 0;
+    return 0;
+  }
+  if (std::string(key) == "frag") {
+    // the one-term filter's copy in MFMA-fragment order (match_g1_kernel) or row-major (match_b1_kernel): same answers.
+    // The copy is rewritten in the other layout by the next dif_match (or dif_gallery_set).
+    h->g.frag = value != 0;
     return 0;
   }
   if (std::string(key) == "filter") {

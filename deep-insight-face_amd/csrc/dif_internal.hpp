@@ -23,7 +23,8 @@ struct Gallery {
   int64_t index_base = 0;   // global index of row 0 (gallery sharded across ranks)
   float* rows = nullptr;    // [n][d]
   float* rows2 = nullptr;   // the same rows as two bf16 planes per K-step of 32, [n][d/32][hi 32 | mid 32] (the filter's operand)
-  uint16_t* rows1 = nullptr;// the same rows rounded to bf16, [n][d] (the one-term filter's operand: "filter" = 2)
+  uint16_t* rows1 = nullptr;// the same rows rounded to bf16 (the one-term filter's operand: "filter" = 2), capacity rounded up to 64 rows:
+                            // [n][d] for match_b1_kernel, or -- rows1_frag -- in MFMA-fragment order for match_g1_kernel
   float* probes2 = nullptr; // this call's probes in the filter's form (probes2_cap rows of d floats)
   size_t probes2_cap = 0;
   float* sq = nullptr;      // |g|^2
@@ -50,6 +51,8 @@ struct Gallery {
   bool rows2_valid = false;        // rows2 holds the split of the CURRENT rows
   bool rows2_refused = false;      // its allocation failed for this capacity: the f32 filter serves, no retry per call
   bool rows1_valid = false, rows1_refused = false;   // the same two states for rows1
+  bool frag = true;                // "frag" = 1 (default): rows1 in fragment order where the embedding size allows it (match.hip: g1_dims)
+  bool rows1_frag = false;         // the layout rows1 was last filled in
   bool filter_one = true;          // "filter" = 2 (default): one bf16 term per operand (match_b1_kernel), a wider net re-ranked; 1: two terms
   bool filter_bf2 = true;          // the MFMA filter runs on bf16 operands (dif_gallery_set_option "filter" = 0: f32)
   int bd_fill = 1;                 // "bd_fill": blocks of match_bd_kernel per resident slot (development: no effect measured, r04)
