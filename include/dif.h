@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DIF_VERSION 110 /* 1.1: + dif_gallery_update / _reserve / _capacity, dif_*_option_name, option "sk2" */
+#define DIF_VERSION 110 /* 1.1: + dif_gallery_update / _reserve / _capacity, dif_*_option_name, options "sk2", "mt"; gallery option "frag" */
 
 /* distance metrics: evaluation/utility.py:52-66 */
 #define DIF_METRIC_SQL2 0   /* sum((a-b)^2, axis=1)                     utility.py:53-56 */
@@ -167,6 +167,10 @@ int64_t dif_gallery_capacity(const dif_gallery* g);
  * the first dif_match after the option changed; changing it frees the copy the new filter does not read (in either
  * order with dif_gallery_set); when a copy cannot be allocated the f32 filter serves and nothing fails
  * (dif_gallery_get_stat "split_copy" / "filter_terms" tell).
+ * "frag": 1 (default) the one-term copy ("filter" = 2) is kept in MFMA-fragment order and the filter runs on
+ * match_g1_kernel (the probes resident in LDS, the gallery streamed once from HBM straight into the MFMA operand
+ * registers) where the embedding size is a multiple of 128 up to 512; 0: row-major, match_b1_kernel.  Same answers,
+ * same bytes per row; the copy is rewritten in the other layout by the next dif_match / dif_gallery_set.
  * "clamp_nan": 0 (default) dif_match reports NaN where the reference's distance is NaN; 1 reports the
  * distance of the similarity clamped to [-1, 1] instead (0 for a similarity rounded above 1, 1 below -1).  The
  * arg-min is the reference's either way.

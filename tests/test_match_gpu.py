@@ -292,15 +292,19 @@ def test_match_near_ties_vs_golden(cuda, golden_dir, metric):
     # kernel (match_bd_kernel) and, 'bd' = 0, its match_tile_kernel.  Every copy of a probe must get the fixture's answer.
     rep = np.concatenate([probes, probes, probes, probes[:16]])
     want_rep = np.concatenate([g['idx%d' % metric]] * 3 + [g['idx%d' % metric][:16]])
-    for flt, bd in ((2, 1), (1, 1), (1, 0)):
+    # ... and the one-term filter on its row-major copy ('frag' = 0: match_b1_kernel) as well as on the fragment-order one
+    # (match_g1_kernel, the default where the embedding size allows it: it served every call above)
+    for flt, bd, frag in ((2, 1, 1), (2, 1, 0), (1, 1, 1), (1, 0, 1)):
         gal.set_option('filter', flt)
         gal.set_option('bd', bd)
+        gal.set_option('frag', frag)
         i5, d5 = gal.match(rep, metric)
         assert np.array_equal(i5, want_rep), (flt, bd, np.nonzero(i5 != want_rep)[0])
         assert np.array_equal(d5[:48], dist, equal_nan=True)
         i4, d4, k4 = gal.match(probes, metric, return_key=True)
         assert np.array_equal(i4, idx) and np.array_equal(d4, dist, equal_nan=True) and np.array_equal(k4, key)
     gal.set_option('bd', 1)
+    gal.set_option('frag', 1)
     # the filter stage on the f32 MFMA instead of bf16 operands: the same answers, bit for bit (the filter only
     # proposes candidates; the reference arithmetic decides)
     gal.set_option('filter', 0)
@@ -368,10 +372,11 @@ def test_match_degenerate_vs_golden(cuda, golden_dir, name):
             assert np.abs(dist[~nan].view(np.int32).astype(np.int64) - want_d[~nan].view(np.int32)).max() <= 4
         # more than 64 probes (the fixture's, repeated): match_b1_kernel / match_bd_kernel and their wave-local epilogue
         reps = (80 + B - 1) // B + 1
-        for flt in (2, 1):
+        for flt, frag in ((2, 1), (2, 0), (1, 1)):               # frag 1 / 0: match_g1_kernel / match_b1_kernel
             gal.set_option('filter', flt)
+            gal.set_option('frag', frag)
             i6, d6 = gal.match(np.concatenate([probes] * reps), metric)
-            assert np.array_equal(i6, np.concatenate([want_i] * reps)), (metric, 'filter', flt)
+            assert np.array_equal(i6, np.concatenate([want_i] * reps)), (metric, 'filter', flt, frag)
             assert np.array_equal(np.isnan(d6), np.concatenate([nan] * reps))
         # ragged groups of probes (other tile shapes), on every filter (f32, two-term, one-term)
         for flt in (0, 1, 2):
@@ -572,8 +577,12 @@ def test_match_bd_kernel_equals_tile_kernel(cuda, G, B):
     probes[B // 3] = -gal_t[5]                                                  # an anti-parallel pair
     g = oneshot.Gallery(gal_t)
     for metric in (0, 1):
-        g.set_option('filter', 2)                   # the default: one-term bf16 filter, match_b1_kernel
+        g.set_option('filter', 2)                   # the default: one-term bf16 filter, match_g1_kernel on the fragment-order copy
         i2, d2, k2 = g.match(probes, metric, return_key=True)
+        g.set_option('frag', 0)                     # ... and match_b1_kernel on the row-major copy (rebuilt by this call)
+        i3, d3, k3 = g.match(probes, metric, return_key=True)
+        g.set_option('frag', 1)
+        assert torch.equal(i2, i3) and torch.equal(d2.view(torch.int32), d3.view(torch.int32)) and torch.equal(k2.view(torch.int32), k3.view(torch.int32))
         g.set_option('filter', 1)
         g.set_option('bd', 1)
         i1, d1, k1 = g.match(probes, metric, return_key=True)
@@ -687,4 +696,46 @@ def test_probe_workspace_survives_a_non_monotone_batch_sequence(cuda):
         assert torch.equal(i, pick[:B]), B
     torch.cuda.synchronize()
     assert bool((guard == 7.0).all())
+    g.close()
+
+
+@pytest.mark.parametrize('D', [128, 256, 384, 512, 192])
+def test_fragment_order_copy_follows_updates_and_reserve(cuda, D):
+    """The one-term filter's copy in MFMA-fragment order (gallery option 'frag', match_g1_kernel; embedding sizes that are
+    multiples of 128 up to 512 -- 192 stays row-major on match_b1_kernel): enrolled whole (staged 8 rows at a time), updated in
+    ragged runs that straddle 8-, 32- and 64-row boundaries (piece by piece), appended to past a reserve (the copy is moved),
+    switched to the row-major layout and back (rebuilt by the next match) -- after every step the answers equal the f32
+    filter's, bit for bit, and 'frag' = 0 gives the same."""
+    from deep_insight_face import oneshot
+    gen = torch.Generator(device='cuda').manual_seed(D)
+    G, B = 5000, 150
+    rows = torch.nn.functional.normalize(torch.randn((G + 700, D), device='cuda', generator=gen), dim=1)
+    g = oneshot.Gallery(rows[:G])
+
+    def check(n, tag):
+        pick = torch.randperm(n, device='cuda', generator=gen)[:B]
+        probes = torch.nn.functional.normalize(rows_now[pick] + 0.05 * torch.randn((B, D), device='cuda', generator=gen), dim=1)
+        out = {}
+        for name, flt, frag in (('g1', 2, 1), ('b1', 2, 0), ('f32', 0, 1)):
+            g.set_option('filter', flt)
+            g.set_option('frag', frag)
+            out[name] = [g.match(probes, m, return_key=True) for m in (0, 1)]
+        g.set_option('filter', 2)
+        g.set_option('frag', 1)
+        for name in ('g1', 'b1'):
+            for (i, d, k), (i0, d0, k0) in zip(out[name], out['f32']):
+                assert torch.equal(i, i0) and torch.equal(d.view(torch.int32), d0.view(torch.int32)), (tag, name)
+        assert torch.equal(out['g1'][1][0], pick), tag
+
+    rows_now = rows[:G].clone()
+    check(G, 'set')
+    for first, count in ((3, 1), (29, 7), (60, 9), (1000, 333), (G - 5, 5)):
+        new = torch.nn.functional.normalize(torch.randn((count, D), device='cuda', generator=gen), dim=1)
+        g.update(new, first)
+        rows_now[first:first + count] = new
+    check(G, 'updated')
+    g.reserve(G + 700)
+    g.update(rows[G:G + 700], G)
+    rows_now = torch.cat([rows_now, rows[G:G + 700]])
+    check(G + 700, 'appended')
     g.close()
