@@ -235,7 +235,8 @@ int dif_gallery_set_option(dif_gallery* h, const char* key, int value) {
   if (std::string(key) == "frag") {
     // the one-term filter's copy in MFMA-fragment order (match_g1_kernel) or row-major (match_b1_kernel): same answers.
     // The copy is rewritten in the other layout by the next dif_match (or dif_gallery_set).
-    h->g.frag = value != 0;
+    if (value < 0 || value > 2) return set_error("dif_gallery_set_option: 'frag' takes 0, 1 or 2");
+    h->g.frag = value;
     return 0;
   }
   if (std::string(key) == "filter") {
@@ -274,6 +275,10 @@ int dif_gallery_get_stat(dif_gallery* h, const char* key, int64_t* out, void* st
   }
   if (k == "filter_terms") {                   // what the next dif_match's filter stage runs on: 0 f32 rows, 2 / 1 bf16 terms per operand
     *out = (g.filter_bf2 && g.filter_one && g.rows1 && g.rows1_valid) ? 1 : ((g.filter_bf2 && g.rows2 && g.rows2_valid) ? 2 : 0);
+    return 0;
+  }
+  if (k == "frag_copy") {                      // 1: the one-term copy is held in fragment order (the next dif_match runs match_g1_kernel)
+    *out = (g.filter_bf2 && g.filter_one && g.rows1 && g.rows1_valid && g.rows1_frag) ? 1 : 0;
     return 0;
   }
   if (k == "row_bytes") {                      // device bytes held per gallery row

@@ -51,7 +51,8 @@ struct Gallery {
   bool rows2_valid = false;        // rows2 holds the split of the CURRENT rows
   bool rows2_refused = false;      // its allocation failed for this capacity: the f32 filter serves, no retry per call
   bool rows1_valid = false, rows1_refused = false;   // the same two states for rows1
-  bool frag = true;                // "frag" = 1 (default): rows1 in fragment order where the embedding size allows it (match.hip: g1_dims)
+  int frag = 1;                    // "frag": rows1 in fragment order -- 1 (default) where the embedding size allows it (match.hip: g1_dims) and the
+                                   // gallery is large enough to give every wave of match_g1_kernel a few tiles, 2 whatever its size, 0 never
   bool rows1_frag = false;         // the layout rows1 was last filled in
   bool filter_one = true;          // "filter" = 2 (default): one bf16 term per operand (match_b1_kernel), a wider net re-ranked; 1: two terms
   bool filter_bf2 = true;          // the MFMA filter runs on bf16 operands (dif_gallery_set_option "filter" = 0: f32)

@@ -7,6 +7,7 @@ probe row q, ``np.argmin(evaluation.utility.distance(q[None, :], gallery, metric
 (evaluation/utility.py:52-66 broadcast over the gallery; first minimum wins).
 """
 import ctypes
+import os
 
 import torch
 
@@ -28,6 +29,11 @@ class Gallery:
             raise ValueError('Gallery needs embeddings or emd_size')
         N.check(N.lib.dif_gallery_create(ctypes.byref(self._h), int(emd_size)), ValueError)
         self.emd_size = int(emd_size)
+        # development hook (A/B runs of bench.py and the tools, like DIF_OPTIONS for the networks): "key=value,..." applied to
+        # every gallery of the process at creation
+        for kv in os.environ.get('DIF_GALLERY_OPTIONS', '').split(','):
+            if '=' in kv:
+                self.set_option(kv.split('=')[0].strip(), int(kv.split('=')[1]))
         if embeddings is not None:
             self.set(embeddings, index_base)
 
@@ -70,6 +76,8 @@ class Gallery:
     def set_option(self, key, value):
         """'filter': 2 (default) runs the MFMA filter stage on operands rounded to bf16 once, 1 on two-term split-bf16
         operands, 0 in float32: the same results (the filter only proposes candidates), different speed and memory.
+        'frag': layout of the one-term filter's copy -- 1 (default) MFMA-fragment order from 2^18 rows up (embedding sizes that
+        are multiples of 128 up to 512), 2 always, 0 row-major; same results (include/dif.h).
         'clamp_nan': 1 reports distance 0 / 1 where the reference's distance is NaN (a similarity rounded
         beyond +-1); the default 0 reports NaN like the reference.  The arg-min is unaffected."""
         N.check(N.lib.dif_gallery_set_option(self._h, key.encode(), int(value)), ValueError)
@@ -78,6 +86,7 @@ class Gallery:
         """'split_copy': 1 when the filter's bf16 copy of the rows exists (+ 50 % device memory for the one-term
         filter, + 100 % for the two-term one; when it cannot be allocated the float32 filter serves);
         'filter_terms': bf16 terms per operand the next match's filter runs on (0: float32 rows);
+        'frag_copy': 1 when the one-term copy is held in MFMA-fragment order (option 'frag': match_g1_kernel serves);
         'row_bytes': device bytes per row;
         'exact_probes': probes the last match sent to the exact whole-gallery search (synchronises)."""
         v = ctypes.c_int64(0)

@@ -169,8 +169,10 @@ int64_t dif_gallery_capacity(const dif_gallery* g);
  * (dif_gallery_get_stat "split_copy" / "filter_terms" tell).
  * "frag": 1 (default) the one-term copy ("filter" = 2) is kept in MFMA-fragment order and the filter runs on
  * match_g1_kernel (the probes resident in LDS, the gallery streamed once from HBM straight into the MFMA operand
- * registers) where the embedding size is a multiple of 128 up to 512; 0: row-major, match_b1_kernel.  Same answers,
- * same bytes per row; the copy is rewritten in the other layout by the next dif_match / dif_gallery_set.
+ * registers) where the embedding size is a multiple of 128 up to 512 and the gallery holds at least 2^18 rows (below,
+ * that kernel's waves would not get a tile each); 2: whatever the row count; 0: row-major, match_b1_kernel.  Same
+ * answers, same bytes per row; the copy is rewritten in the other layout by the next dif_match / dif_gallery_set
+ * (also when dif_gallery_update takes the row count across the threshold).
  * "clamp_nan": 0 (default) dif_match reports NaN where the reference's distance is NaN; 1 reports the
  * distance of the similarity clamped to [-1, 1] instead (0 for a similarity rounded above 1, 1 below -1).  The
  * arg-min is the reference's either way.
@@ -181,6 +183,7 @@ int64_t dif_gallery_capacity(const dif_gallery* g);
 int dif_gallery_set_option(dif_gallery* g, const char* key, int value);
 /* read-outs (no reference counterpart; for capacity planning and tests).  "split_copy": 1 when the filter's bf16 copy
  * of the current rows exists; "filter_terms": bf16 terms per operand the next dif_match's filter runs on (1 or 2; 0 = the f32 rows);
+ * "frag_copy": 1 when that copy is held in MFMA-fragment order (gallery option "frag");
  * "row_bytes": device bytes held per gallery row; "exact_probes": how many probes the
  * last dif_match on `stream` sent to the exact whole-gallery search (synchronises the stream). */
 int dif_gallery_get_stat(dif_gallery* g, const char* key, int64_t* out, void* stream);

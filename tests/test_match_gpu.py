@@ -294,7 +294,7 @@ def test_match_near_ties_vs_golden(cuda, golden_dir, metric):
     want_rep = np.concatenate([g['idx%d' % metric]] * 3 + [g['idx%d' % metric][:16]])
     # ... and the one-term filter on its row-major copy ('frag' = 0: match_b1_kernel) as well as on the fragment-order one
     # (match_g1_kernel, the default where the embedding size allows it: it served every call above)
-    for flt, bd, frag in ((2, 1, 1), (2, 1, 0), (1, 1, 1), (1, 0, 1)):
+    for flt, bd, frag in ((2, 1, 2), (2, 1, 0), (1, 1, 1), (1, 0, 1)):
         gal.set_option('filter', flt)
         gal.set_option('bd', bd)
         gal.set_option('frag', frag)
@@ -372,7 +372,7 @@ def test_match_degenerate_vs_golden(cuda, golden_dir, name):
             assert np.abs(dist[~nan].view(np.int32).astype(np.int64) - want_d[~nan].view(np.int32)).max() <= 4
         # more than 64 probes (the fixture's, repeated): match_b1_kernel / match_bd_kernel and their wave-local epilogue
         reps = (80 + B - 1) // B + 1
-        for flt, frag in ((2, 1), (2, 0), (1, 1)):               # frag 1 / 0: match_g1_kernel / match_b1_kernel
+        for flt, frag in ((2, 2), (2, 0), (1, 1)):               # frag 2 / 0: match_g1_kernel / match_b1_kernel
             gal.set_option('filter', flt)
             gal.set_option('frag', frag)
             i6, d6 = gal.match(np.concatenate([probes] * reps), metric)
@@ -579,8 +579,11 @@ def test_match_bd_kernel_equals_tile_kernel(cuda, G, B):
     for metric in (0, 1):
         g.set_option('filter', 2)                   # the default: one-term bf16 filter, match_g1_kernel on the fragment-order copy
         i2, d2, k2 = g.match(probes, metric, return_key=True)
-        g.set_option('frag', 0)                     # ... and match_b1_kernel on the row-major copy (rebuilt by this call)
+        g.set_option('frag', 2)                     # ... match_g1_kernel on the fragment-order copy whatever the gallery's size (rebuilt by this call)
         i3, d3, k3 = g.match(probes, metric, return_key=True)
+        g.set_option('frag', 0)                     # ... and match_b1_kernel on the row-major one
+        i4, d4, k4 = g.match(probes, metric, return_key=True)
+        assert torch.equal(i2, i4) and torch.equal(d2.view(torch.int32), d4.view(torch.int32)) and torch.equal(k2.view(torch.int32), k4.view(torch.int32))
         g.set_option('frag', 1)
         assert torch.equal(i2, i3) and torch.equal(d2.view(torch.int32), d3.view(torch.int32)) and torch.equal(k2.view(torch.int32), k3.view(torch.int32))
         g.set_option('filter', 1)
@@ -710,18 +713,20 @@ def test_fragment_order_copy_follows_updates_and_reserve(cuda, D):
     gen = torch.Generator(device='cuda').manual_seed(D)
     G, B = 5000, 150
     rows = torch.nn.functional.normalize(torch.randn((G + 700, D), device='cuda', generator=gen), dim=1)
-    g = oneshot.Gallery(rows[:G])
+    g = oneshot.Gallery(emd_size=D)
+    g.set_option('frag', 2)                                   # (1, the default, keeps galleries below 2^18 rows row-major)
+    g.set(rows[:G])
 
     def check(n, tag):
         pick = torch.randperm(n, device='cuda', generator=gen)[:B]
         probes = torch.nn.functional.normalize(rows_now[pick] + 0.05 * torch.randn((B, D), device='cuda', generator=gen), dim=1)
         out = {}
-        for name, flt, frag in (('g1', 2, 1), ('b1', 2, 0), ('f32', 0, 1)):
+        for name, flt, frag in (('g1', 2, 2), ('b1', 2, 0), ('f32', 0, 1)):
             g.set_option('filter', flt)
             g.set_option('frag', frag)
             out[name] = [g.match(probes, m, return_key=True) for m in (0, 1)]
         g.set_option('filter', 2)
-        g.set_option('frag', 1)
+        g.set_option('frag', 2)
         for name in ('g1', 'b1'):
             for (i, d, k), (i0, d0, k0) in zip(out[name], out['f32']):
                 assert torch.equal(i, i0) and torch.equal(d.view(torch.int32), d0.view(torch.int32)), (tag, name)
@@ -739,3 +744,34 @@ def test_fragment_order_copy_follows_updates_and_reserve(cuda, D):
     rows_now = torch.cat([rows_now, rows[G:G + 700]])
     check(G + 700, 'appended')
     g.close()
+
+
+def test_fragment_layout_follows_the_row_count(cuda):
+    """Gallery option 'frag' = 1 (the default): the one-term copy is kept in fragment order -- and the filter runs on
+    match_g1_kernel -- from 2^18 rows up; a gallery that grows past the threshold by updates has its copy rewritten by the
+    next match.  Same answers either side of it."""
+    from deep_insight_face import oneshot
+    gen = torch.Generator(device='cuda').manual_seed(18)
+    D, G0, G1 = 128, (1 << 18) - 100, (1 << 18) + 150
+    rows = torch.nn.functional.normalize(torch.randn((G1, D), device='cuda', generator=gen), dim=1)
+    pick = torch.randperm(G0, device='cuda', generator=gen)[:70]
+    probes = torch.nn.functional.normalize(rows[pick] + 0.05 * torch.randn((70, D), device='cuda', generator=gen), dim=1)
+    g = oneshot.Gallery(emd_size=D)
+    g.reserve(G1)
+    g.update(rows[:G0], 0)
+    i0, d0 = g.match(probes, 1)
+    assert g.stat('frag_copy') == 0 and g.stat('filter_terms') == 1
+    assert torch.equal(i0, pick)
+    g.update(rows[G0:G1])                                        # across the threshold: the copy is stale in its layout ...
+    i1, d1 = g.match(probes, 1)                                  # ... and rewritten here
+    assert g.stat('frag_copy') == 1 and g.stat('filter_terms') == 1
+    assert torch.equal(i1, i0) and torch.equal(d1.view(torch.int32), d0.view(torch.int32))
+    big = oneshot.Gallery(rows)                                  # enrolled whole: fragment order from the start
+    assert big.stat('frag_copy') == 1
+    i2, d2 = big.match(probes, 1)
+    assert torch.equal(i2, i0) and torch.equal(d2.view(torch.int32), d0.view(torch.int32))
+    big.set_option('frag', 0)
+    i3, d3 = big.match(probes, 1)
+    assert big.stat('frag_copy') == 0 and torch.equal(i3, i0) and torch.equal(d3.view(torch.int32), d0.view(torch.int32))
+    g.close()
+    big.close()

@@ -101,7 +101,7 @@ def main():
                     one['roofline']['frac']))
     # the match filter kernel of the same profiled run: per-launch duration from the stats vs the HIP-event match phase
     for r in csv.DictReader(open(os.path.join(OUT, 'ks_default_1lane/p_kernel_stats.csv'))):
-        if 'match_b1_kernel' in r['Name'] or 'match_bd_kernel' in r['Name']:
+        if 'match_g1_kernel' in r['Name'] or 'match_b1_kernel' in r['Name'] or 'match_bd_kernel' in r['Name']:
             lines.append('%s in that run: %s calls, %.1f us average (kernel-trace stats) vs match phase %.3f ms by HIP events '
                          '(the phase also holds probe_prep1 / finish / exact / output)'
                          % (r['Name'].split('(')[0].split('::')[-1], r['Calls'], float(r['AverageNs']) / 1e3, one['phases_ms']['match']))
