@@ -1,6 +1,7 @@
 // Embedding network: a static list of layer ops over pooled NHWC activation buffers,
 // executed as a fixed sequence of kernel launches on the caller's stream.
 #pragma once
+#include <stdlib.h>
 #include <algorithm>
 #include <map>
 #include <string>
@@ -110,6 +111,7 @@ struct Net {
   int64_t output_elems() const { return output_offset(-2); }
   // images from which a forward is worth splitting over two lanes: 64 at 112 x 112, fewer for larger inputs (the detector)
   int lane_min_images() const {
+    if (const char* e = getenv("DIF_LANE_MIN_IMAGES")) return atoi(e) > 2 ? atoi(e) : 2;   // development: A/B of the split threshold
     const int64_t px = (int64_t)in_h * in_w;
     const int64_t m = (64LL * 112 * 112 + px - 1) / (px > 0 ? px : 1);
     return m < 2 ? 2 : (m > 64 ? 64 : (int)m);
