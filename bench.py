@@ -713,6 +713,9 @@ def main():
                 'forward_ms_hip_events': embed_ms,
                 'conv_only': {'ms': conv_ms, 'tflops': conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms else None},
                 'match': {'ms': match_ms, 'tflops': m_flops / (match_ms * 1e-3) / 1e12,
+                          'kernel': ('match_g1_kernel (probes resident in LDS, gallery copy in MFMA-fragment order streamed into registers)'
+                                     if shard.gallery.stat('frag_copy') else
+                                     {1: 'match_b1_kernel', 2: 'match_bd_kernel / match_tile_kernel', 0: 'match_tile_kernel'}[filt]),
                           'filter': {1: 'bf16 (one term per operand, one v_mfma_f32_32x32x16_bf16 per 16 k; candidates within the '
                                         'proven bound re-ranked in the reference arithmetic)',
                                      2: 'bf16x2 (two bf16 terms per operand, three v_mfma_f32_32x32x16_bf16 per 16 k)',

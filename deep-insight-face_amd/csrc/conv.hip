@@ -2087,297 +2087,9 @@ static int launch_conv_t2(const ConvArgs& a, hipStream_t st) {
   return 0;
 }
 
-// ------------------------------------------------------------------------------------------
-// conv_pw_kernel: the pointwise (1 x 1 / stride 1) convolution as a BARRIER-FREE GEMM (round 4).
-//
-// ResNet-50V2 is 36 such layers out of 53 convolutions.  On conv_igemm / conv_pipe they stage both operands global ->
-// registers -> LDS and meet at one barrier per 32-k step; with K of 2-64 steps per tile that chain (and the per-tile
-// prologue behind it) is what the layers wait for (profiles/r03_ablation.txt item 21).  Here NOTHING is shared between
-// the waves of a block but the pre-activation table, so there is no barrier after the first instruction:
-//   * a wave owns 32 output pixels x 32 WN output channels.  Its 32 input rows ([pixels][Cin], a plain matrix) arrive
-//     by LDS-DMA (buffer_load ... lds, no staging registers) in a PRIVATE ring of three 4 KB K-step stages, two K-steps
-//     ahead; rows are 128 bytes, XOR-swizzled through the source address (chunk c of row r at slot c ^ ((r >> 1) & 7))
-//     so that the fragment reads are conflict-free.  LDS is used as the coalescing transposer it is -- a lane of the A
-//     operand wants 32 bytes of ITS row -- not as shared memory;
-//   * the weights come from L2 in MFMA-fragment order (ConvArgs::w_frag, the B-direct layout of the 3x3 layers) straight
-//     into the operand registers through a ring of four 16-k sub-step sets, three sub-steps ahead; the waves of a CU
-//     fetch the same fragments and find them in its L1;
-//   * both streams run the same distance ahead, so the in-order vmcnt never makes one wait for the other: the wait that
-//     covers a B set issued in step ks - 2 covers the rows of step ks, issued before it; one explicit s_waitcnt in front
-//     of the fragment reads states that to the compiler (it cannot see the DMA's LDS write);
-//   * pre-activation (ResNet-50V2's relu(preact_bn(x)), which feeds only these layers and is never stored) is applied
-//     to the A fragments in registers, constants from an LDS table filled once per block;
-//   * epilogue straight from the MFMA layout, per wave: a lane holds ONE output channel (its constants sit in six
-//     registers) and every accumulator register is stored as it stands -- 32 channels x two pixels per instruction =
-//     two 128-byte segments, the full-rate store shape (DESIGN.md "First layers"); the shortcut is read the same way.
-// The products of an output element are accumulated in exactly the order of conv_igemm_kernel (K-step, sub-step, t; the
-// same k permutation), so the results are bit-identical (tests: option "pw" 0 / 1).
-template <int WN_, int WGM_, int WGN_, int NS_, int OCC_>
-struct PwTile {
-  static constexpr int WN = WN_, WGM = WGM_, WGN = WGN_, OCC = OCC_;
-  static constexpr int NW = WGM * WGN, NT = 64 * NW;
-  static constexpr int BM = 32 * WGM, BN = 32 * WN * WGN;
-  static constexpr int NS = NS_;                            // K-step stages per wave: the rows run NS - 1 K-steps ahead
-  static constexpr int LA = NS - 1;
-  static constexpr int LB = NS == 3 ? 3 : 1;                // sub-steps the B fragments run ahead (<= 2 LA: see the kernel)
-  static constexpr int RING = LB + 1;                       // B register sets (divides the four sub-steps of a loop turn)
-  static constexpr int RING_B = NS * 4096;                  // bytes per wave
-  // VMEM operations certainly younger than the rows of step ks when step ks begins (its own DMA issued): the LA stages
-  // behind them and the B sets of the sub-steps in between -- in the loop 4 LA WN loads, at the first step the prologue's 2 LB WN
-  static constexpr int VMCNT = 4 * LA + (4 * LA * WN < 2 * LB * WN ? 4 * LA * WN : 2 * LB * WN);
-};
-
-template <class T, bool PRE>
-__global__ __launch_bounds__(T::NT, T::OCC * T::NW / 4) void conv_pw_kernel(const ConvArgs a, int tiles_n, int ntiles) {
-  constexpr int WN = T::WN;
-  extern __shared__ __attribute__((aligned(16))) char pw_smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave / T::WGN, wc = wave % T::WGN;
-  const int KS = a.Cin / BK;
-  char* ring = pw_smem + wave * T::RING_B;
-  const float* tab = reinterpret_cast<const float*>(pw_smem + T::NW * T::RING_B);   // [Cin] scale, [Cin] shift
-  if constexpr (PRE) {
-    float* t = reinterpret_cast<float*>(pw_smem + T::NW * T::RING_B);
-    for (int c = tid; c < a.Cin; c += T::NT) {
-      t[c] = a.pre_scale[c];
-      t[a.Cin + c] = a.pre_shift[c];
-    }
-    __syncthreads();                                         // the kernel's only barrier
-  }
-  // Persistent: block b takes tiles xcd_remap(b), + P, + 2 P, ... (column tile fastest: the blocks of an XCD hold the column
-  // tiles of the same rows at the same time) and the two operand streams run on ACROSS tiles -- the first rows and B sets
-  // of the next tile are requested in the last step(s) of the current one and land under its epilogue.
-  const int P = (int)gridDim.x;
-  const uint32_t rowb = (uint32_t)a.Cin * 4u;
-  struct Ref {
-    __amdgpu_buffer_rsrc_t xrs;
-    uint32_t boff[WN];
-    int m0, n0;
-  };
-  auto setup = [&](int t, Ref& r) {                          // t >= ntiles: an empty tile (zero rows; never finished)
-    const int tt = t < ntiles ? t : 0;
-    const int mt = tt / tiles_n, nt = tt - mt * tiles_n;
-    r.m0 = mt * T::BM + wr * 32;
-    r.n0 = nt * T::BN + wc * 32 * WN;
-    int rows = t < ntiles ? a.M - r.m0 : 0;
-    rows = rows < 0 ? 0 : (rows < 32 ? rows : 32);
-    r.xrs = make_rsrc(a.x + (int64_t)(rows ? r.m0 : 0) * a.Cin, (uint32_t)rows * rowb);
-#pragma unroll
-    for (int n = 0; n < WN; ++n) r.boff[n] = (uint32_t)((r.n0 >> 5) + n) * (uint32_t)KS * 4096u + (uint32_t)lane * 16u;
-  };
-  // --- A: this wave's 32 rows.  A stage = 4 pieces of 8 rows x 128 B, lane-linear in LDS; piece j holds rows 8 j + (lane >> 3)
-  uint32_t voff[2];                                          // the swizzle term depends on the piece's parity only
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int r = 8 * j + (lane >> 3);
-    voff[j] = (uint32_t)r * rowb + (uint32_t)(((lane & 7) ^ ((r >> 1) & 7)) * 16);
-  }
-  auto dma = [&](const __amdgpu_buffer_rsrc_t& xrs, int ks, int stage) {
-    char* dst = ring + stage * 4096;
-    uint32_t v0 = voff[0], v1 = voff[1];
-    asm volatile("" : "+v"(v0), "+v"(v1));
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, lds_ptr_of(dst + j * 1024), 16, ((j & 1) ? v1 : v0) + (uint32_t)(j >> 1) * 16u * rowb,
-                                               (uint32_t)ks * 128u, 0, 0);
-  };
-  // --- B: fragment-order weights, [Cout / 32][KS][s 2][u 2][lane 64][4 floats]
-  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.w_frag, a.w_frag_bytes);
-  f32x4 bq[T::RING][WN][2];
-  auto bload = [&](const uint32_t (&boff)[WN], int u, f32x4 (&b)[WN][2]) {     // sub-step u = 2 ks + s of the tile boff addresses
-    const uint32_t so = (uint32_t)u * 2048u;
-#pragma unroll
-    for (int n = 0; n < WN; ++n)
-#pragma unroll
-      for (int q = 0; q < 2; ++q) b[n][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, boff[n], so + (uint32_t)q * 1024u, 0));
-  };
-  // --- A fragments: lane (i = lane & 31, h = lane >> 5) holds row i, k = 16 s + 8 h + 4 q + t
-  const int x7 = ((lane & 31) >> 1) & 7, hh = lane >> 5;
-  uint32_t aoff[2][2];
-#pragma unroll
-  for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-    for (int q = 0; q < 2; ++q) aoff[s2][q] = (uint32_t)((lane & 31) * 128 + (((4 * s2 + 2 * hh + q) ^ x7) * 16));
-  f32x16 acc[WN];
-  const int pre_act = a.pre_act;
-  auto substep = [&](int ks, int stage, int s2, const f32x4 (&b)[WN][2]) {
-    f32x4 fa[2];
-    const char* st = ring + stage * 4096;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) fa[q] = *reinterpret_cast<const f32x4*>(st + aoff[s2][q]);
-    if constexpr (PRE) {
-      const int c0 = ks * BK + 16 * s2 + 8 * hh;
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const f32x4 cs = *reinterpret_cast<const f32x4*>(tab + c0 + 4 * q);
-        const f32x4 ct = *reinterpret_cast<const f32x4*>(tab + a.Cin + c0 + 4 * q);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float v = fmaf(fa[q][e], cs[e], ct[e]);
-          if (pre_act == ACT_RELU) v = fmaxf(v, 0.f);
-          fa[q][e] = v;
-        }
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-      for (int n = 0; n < WN; ++n)
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t >> 2][t & 3], b[n][t >> 2][t & 3], acc[n], 0, 0, 0);
-  };
-  const uint32_t obytes = (uint32_t)a.M * (uint32_t)a.Cout * 4u;
-  const __amdgpu_buffer_rsrc_t y_rsrc = make_rsrc(a.y, a.y ? obytes : 0u);
-  const __amdgpu_buffer_rsrc_t y2_rsrc = make_rsrc(a.y2, a.y2 ? obytes : 0u);
-  const __amdgpu_buffer_rsrc_t res_rsrc = make_rsrc(a.res, a.res ? obytes : 0u);
-  const bool has_res = a.res != nullptr;
-  const int act = a.act, act2 = a.act2;
-
-  int tile = xcd_remap((int)blockIdx.x, P);
-  if (tile >= ntiles) return;                                // (the launcher sizes the grid within the tile count)
-  Ref cur, nxt;
-  setup(tile, cur);
-  int g = 0;                                                 // K-steps done so far, all tiles: step g sits in stage g % NS
-#pragma unroll
-  for (int i = 0; i < T::LA; ++i) dma(cur.xrs, i, i % T::NS);
-#pragma unroll
-  for (int i = 0; i < T::LB; ++i) bload(cur.boff, i, bq[i]);
-  bool first = true;
-  while (tile < ntiles) {
-    setup(tile + P, nxt);
-#pragma unroll
-    for (int n = 0; n < WN; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
-    for (int k2 = 0; k2 < KS; k2 += 2) {                     // two K-steps = four sub-steps per turn: the B ring's phase is fixed
-#pragma unroll
-      for (int d = 0; d < 2; ++d) {
-        const int ks = k2 + d;
-        {
-          const int kk = ks + T::LA;                         // the rows LA steps ahead, of the next tile behind this one's last
-          const bool over = kk >= KS;
-          dma(over ? nxt.xrs : cur.xrs, over ? kk - KS : kk, (g + T::LA) % T::NS);
-        }
-        // the rows of step ks have landed (PwTile::VMCNT).  At a later tile's first LA steps they were requested in front of
-        // the previous tile's epilogue, whose 32 WN stores are younger too: waiting for all but VMCNT would wait for the stores
-        if (!first && ks < T::LA) wait_vmcnt<(36 * WN + 4 < 63 ? 36 * WN + 4 : 63)>();
-        else wait_vmcnt<T::VMCNT>();
-        {
-          const int u = 2 * ks + T::LB;
-          const bool over = u >= 2 * KS;
-          bload(over ? nxt.boff : cur.boff, over ? u - 2 * KS : u, bq[(2 * d + T::LB) % T::RING]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        substep(ks, g % T::NS, 0, bq[(2 * d) % T::RING]);
-        __builtin_amdgcn_sched_barrier(0);
-        {
-          const int u = 2 * ks + 1 + T::LB;
-          const bool over = u >= 2 * KS;
-          bload(over ? nxt.boff : cur.boff, over ? u - 2 * KS : u, bq[(2 * d + 1 + T::LB) % T::RING]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        substep(ks, g % T::NS, 1, bq[(2 * d + 1) % T::RING]);
-        __builtin_amdgcn_sched_barrier(0);
-        ++g;
-      }
-    }
-    // --- epilogue, per wave, from the MFMA layout: lane l holds channel n0 + 32 n + (l & 31) of rows frag_row(l, r)
-#pragma unroll
-    for (int n = 0; n < WN; ++n) {
-      const int c = cur.n0 + 32 * n + (lane & 31);
-      const float sc = a.scale ? a.scale[c] : 1.f, sh = a.shift ? a.shift[c] : 0.f, al = a.alpha ? a.alpha[c] : 0.f;
-      const float sc2 = a.scale2 ? a.scale2[c] : 1.f, sh2 = a.shift2 ? a.shift2[c] : 0.f, al2 = a.alpha2 ? a.alpha2[c] : 0.f;
-      uint32_t off[16];
-      float rv[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = cur.m0 + frag_row(lane, r);
-        off[r] = row < a.M ? ((uint32_t)row * (uint32_t)a.Cout + (uint32_t)c) * 4u : OOB;
-        rv[r] = has_res ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(res_rsrc, off[r], 0, 0)) : 0.f;
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float t = fmaf(acc[n][r], sc, sh);
-        const float tr = fmaxf(t, 0.f), tp = t >= 0.f ? t : t * al;
-        t = act == ACT_RELU ? tr : (act == ACT_PRELU ? tp : (act == ACT_RELU6 ? fminf(tr, 6.f) : t));
-        if (has_res) t += rv[r];
-        float u = fmaf(t, sc2, sh2);
-        const float ur = fmaxf(u, 0.f), up = u >= 0.f ? u : u * al2;
-        u = act2 == ACT_RELU ? ur : (act2 == ACT_PRELU ? up : (act2 == ACT_RELU6 ? fminf(ur, 6.f) : u));
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, t), y_rsrc, off[r], 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, u), y2_rsrc, off[r], 0, 0);
-      }
-    }
-    cur = nxt;
-    tile += P;
-    first = false;
-  }
-  wait_vmcnt<0>();                                           // the stages requested past the last tile (empty rows) land before the wave ends
-}
-
-// Does the barrier-free pointwise kernel take this layer?  1 x 1 / stride 1 / no padding over a dense [pixels][Cin] input,
-// whole 32-channel K-steps (an even number of them: the loop turns two at a time), whole 64-channel column tiles, the
-// weights in fragment order, a plain output (and shortcut) geometry, 32-bit buffer offsets.
-static bool pw_applies(const ConvArgs& a) {
-  if (!(a.off & CONV_OFF_PW)) return false;                 // Net option "pw" = 1 switches it ON (the bit is inverted for this
-                                                            // family: it is off by default -- r04_ablation.txt item 3)
-  if (!(a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad_t == 0 && a.pad_l == 0)) return false;
-  if (a.H != a.Ho || a.W != a.Wo || a.Cin % 64 != 0 || a.Cout % 64 != 0 || !a.w_frag || a.Kpad != a.Cin) return false;
-  if (!(a.y_H == a.Ho && a.y_W == a.Wo && a.y_oy == 0 && a.y_ox == 0 && a.y_ld == a.Cout && a.y_coff == 0) || a.y_sub) return false;
-  if (a.res && (a.res_stride != 1 || a.res_H != a.Ho || a.res_W != a.Wo)) return false;
-  if ((int64_t)a.M * a.Cout * 4 >= 0xFFFFFFF0LL || (int64_t)a.M * a.Cin * 4 >= 0xFFFFFFF0LL) return false;
-  if (a.pre_scale && a.Cin > 4096) return false;            // the pre-activation table lives in LDS
-  // 64 input channels = two K-steps per tile: those layers stream (460 MB in 115 us on ResNet-50V2's 28 x 28 stage) and the
-  // persistent pipelined kernel, which retires a tile's stores under the next tile's loads, moves them 5 % faster
-  if (a.Cin < 128 && !(a.dbg & 8)) return false;
-  if ((a.dbg & 64) && !(a.Cout >= 1024 || a.Cin >= 2048)) return false;     // ablation: only the layers it won on one lane
-  return true;
-}
-
-template <class T, bool PRE>
-static int launch_conv_pw_t(const ConvArgs& a, hipStream_t st) {
-  auto kern = conv_pw_kernel<T, PRE>;
-  const int lds = T::NW * T::RING_B + (PRE ? a.Cin * 8 : 0);
-  if (allow_dynamic_lds(reinterpret_cast<const void*>(kern), T::NW * T::RING_B + 4096 * 8)) return -1;
-  const int tiles_m = (a.M + T::BM - 1) / T::BM, tiles_n = a.Cout / T::BN;
-  const int64_t ntiles = (int64_t)tiles_m * tiles_n;
-  if (ntiles >= 0x7fffffffLL) return set_error("conv: too many tiles");
-  // persistent grid: the resident slots of the WHOLE chip (the blocks are independent: what does not fit beside the other
-  // lane's launch starts as slots come free, as for conv_pipe_kernel), never more blocks than tiles
-  int64_t P = (int64_t)T::OCC * num_cus();
-  // (half the slots when the executor's lanes split the chip: measured slower still, profiles/r04_ablation.txt item 3)
-  if (P > ntiles || (a.dbg & 16)) P = ntiles;               // dbg bit 16: one tile per block (ablation)
-  hipLaunchKernelGGL(kern, dim3((unsigned)P), dim3(T::NT), lds, st, a, tiles_n, (int)ntiles);
-  DIF_HIP(hipGetLastError());
-  static const std::string label = std::string("conv_pw_kernel<") + std::to_string(T::BM) + "x" + std::to_string(T::BN) + ",w32x" +
-                                   std::to_string(32 * T::WN) + ",s" + std::to_string(T::NS) + (PRE ? ",preact>" : ">");
-  g_last_kernel = label.c_str();
-  return 0;
-}
-
-static int launch_conv_pw(const ConvArgs& a, hipStream_t st) {
-  // Shipped form: 128 x 64 blocks = four waves of 32 x 64, two K-step stages per wave (the rows one K-step, the B sets one
-  // sub-step ahead), three blocks per CU.  Measured per layer on ResNet-50V2 at batch 256 against the other forms and
-  // against conv_pipe / conv_igemm (profiles/r04_ablation.txt item 3); the development forms stay selectable through
-  // ConvArgs::dbg & 7 (Net option "dbg") for that table.
-  switch (a.dbg & 7) {
-    case 1: {
-      using T = PwTile<1, 2, 2, 2, 4>;                       // 64 x 64, 2 x 2 waves of 32 x 32, four blocks per CU
-      return a.pre_scale ? launch_conv_pw_t<T, true>(a, st) : launch_conv_pw_t<T, false>(a, st);
-    }
-    case 3: {
-      using T = PwTile<1, 4, 1, 2, 4>;                       // 128 x 32, four waves of 32 x 32, four blocks per CU
-      return a.pre_scale ? launch_conv_pw_t<T, true>(a, st) : launch_conv_pw_t<T, false>(a, st);
-    }
-    case 5: {
-      using T = PwTile<2, 4, 1, 3, 2>;                       // 128 x 64 with three stages (two K-steps ahead), two blocks per CU
-      return a.pre_scale ? launch_conv_pw_t<T, true>(a, st) : launch_conv_pw_t<T, false>(a, st);
-    }
-    default: break;
-  }
-  using T = PwTile<2, 4, 1, 2, 3>;
-  return a.pre_scale ? launch_conv_pw_t<T, true>(a, st) : launch_conv_pw_t<T, false>(a, st);
-}
+// (conv_pw_kernel -- round 4's barrier-free pointwise GEMM: wave-private LDS-DMA ring, weights in fragment order, bit-identical,
+// +2 % on one lane and -8..10 % inside the two-lane executor, never the default -- was removed in round 5: its measurements
+// stay in profiles/r04_ablation.txt item 3 and DESIGN.md section 5; the per-step barrier is not what the pointwise layers wait for.)
 
 // ---- the small-batch split-K path (conv_splitk.hpp)
 // Few tiles with a long K loop: S splits per tile so that the grid is about two blocks per CU, each share at least
@@ -2535,9 +2247,6 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
   // 1x1 / no padding / whole 32-channel K-steps: the pointwise loader
   constexpr bool kDefaultTile = (T::BM == 64 && T::BN == 64);
   const bool pw = a.KH == 1 && a.KW == 1 && a.pad_t == 0 && a.pad_l == 0 && a.Cin % BK == 0;
-  if constexpr (T::BM == 64 && T::BN == 64) {
-    if (pw && pw_applies(a)) return launch_conv_pw(a, st);
-  }
   // (a compile-time specialisation of the 3x3 gather, KMODE 2, was measured 5 % SLOWER than the
   // run-time-selected path on IResNet-100 -- hipcc schedules the loop differently -- so the
   // multi-tap layers stay on the general loader)

@@ -943,7 +943,7 @@ static void fold(const Net* net, const BNRef& bn, int bias, int C, std::vector<f
 // pick between kernel families the parity tests compare)
 // every key set_option accepts (dif_net_option_name: include/dif.h documents each one, and a test holds it to that)
 const char* const* Net::option_names() {
-  static const char* const names[] = {"pipe", "bdp", "stem", "patch", "patch2d", "bd", "t2", "tn", "sk2", "mt", "pw", "bf16x3",
+  static const char* const names[] = {"pipe", "bdp", "stem", "patch", "patch2d", "bd", "t2", "tn", "sk2", "mt", "bf16x3",
                                       "bf_terms", "ysub", "lane_split", "lane_prio", "dbg", nullptr};
   return names;
 }
@@ -973,14 +973,6 @@ int Net::set_option(const char* key, int value) {
   if (!strcmp(key, "tn")) return flag(CONV_OFF_TN);
   if (!strcmp(key, "sk2")) return flag(CONV_OFF_SK2);
   if (!strcmp(key, "mt")) return flag(CONV_OFF_MT);
-  if (!strcmp(key, "pw")) {                                 // conv_pw_kernel is OFF by default: the bit means "on" for this family
-    // its fragment-order weight copy is built at finalize only when the option is on by then (it doubled the
-    // pointwise weights of every net for a path that is off by default): on -> off any time, off -> on before finalize
-    if (value && !pre && !pw_frag_built)
-      return set_error("dif_net_set_option: 'pw' = 1 must be chosen before dif_net_finalize (it needs its own weight layout)");
-    conv_off = value ? (conv_off | CONV_OFF_PW) : (conv_off & ~CONV_OFF_PW);
-    return 0;
-  }
   if (!strcmp(key, "bf16x3")) {
     if (!pre && compute_bf16x3 != (value != 0))
       return set_error("dif_net_set_option: 'bf16x3' must be chosen before dif_net_finalize");
@@ -1093,12 +1085,8 @@ int Net::finalize(int mb) {
       // can take (3x3 / stride 1 / pad 1, whole 32-channel slices)
       op.d_w_frag = nullptr;
       op.w_frag_bytes = 0;
-      // ... and every pointwise layer conv_pw_kernel can take (1x1 / stride 1, whole 64-channel K and column blocks)
-      const bool pw_layer = (conv_off & CONV_OFF_PW) && op.KH == 1 && op.KW == 1 && op.stride == 1 && op.pad_t == 0 && op.pad_l == 0 &&
-                            op.Cin % 64 == 0 && op.Cin_true == op.Cin && op.Cout % 64 == 0 && !op.chw_flatten;
-      if (conv_off & CONV_OFF_PW) pw_frag_built = true;
-      if (pw_layer || (!op.d_w3f && op.k_order == 1 && op.KH == 3 && op.KW == 3 && op.stride == 1 && op.pad_t == 1 && op.pad_l == 1 &&
-          !op.pre_bn.valid())) {
+      if (!op.d_w3f && op.k_order == 1 && op.KH == 3 && op.KW == 3 && op.stride == 1 && op.pad_t == 1 && op.pad_l == 1 &&
+          !op.pre_bn.valid()) {
         const int KS = op.Kpad / BK, NT32 = (op.Cout + 31) / 32;
         std::vector<float> frag((size_t)NT32 * 32 * op.Kpad, 0.f);
         size_t o = 0;

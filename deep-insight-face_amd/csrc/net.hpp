@@ -153,7 +153,6 @@ struct Net {
   int opt_lane_split = -1;          // option "lane_split" (before finalize): -1 by work per launch, 0 / 1 forced
   int opt_lane_prio = 0;            // option "lane_prio" (before finalize): 0 = extra lanes on least-priority streams, 1 = normal
   int conv_dbg = 0;                 // option "dbg": ConvArgs::dbg
-  bool pw_frag_built = false;       // finalize laid out the pointwise layers' weights for conv_pw_kernel (option "pw" was on)
   unsigned conv_off = 0;            // options "patch", "patch2d", "bd" = 0: CONV_OFF_* bits handed to every convolution
   int set_option(const char* key, int value);
   // dif_net_set_option; also applied from DIF_OPTIONS="key=value,..." at finalize

@@ -257,9 +257,6 @@ int dif_net_finalize(dif_net* net, int max_batch);
  *   "mt"         1 (default): at ONE image per call (predictions.py:152-156) a layer runs in one launch on 16 x 16 tiles,
  *                operands straight from L2 into the MFMA registers, K split over the block's waves (conv_minitile.hpp);
  *                0: the split-K pair / the large-batch kernels
- *   "pw"         0 (default); 1 (before dif_net_finalize: it lays the pointwise weights out once more; back to 0 any time):
- *                1x1 / stride 1 layers run on the barrier-free pointwise kernel (conv_pw_kernel: bit-identical, slower
- *                inside the two-lane executor)
  *   "bf16x3"     0 (default): float32 MFMA, a bit-exact f32 fma chain -- the reference's arithmetic;
  *                1 (before dif_net_finalize): throughput mode -- every f32 operand split into bf16 terms, bf16 MFMA
  *                products accumulated in f32 (f32-level accuracy, same 1e-5 cosine gate, not bit-identical)

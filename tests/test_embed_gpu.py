@@ -333,47 +333,6 @@ def test_lean_epilogue_equals_general_epilogue(cuda):
         m.close()
 
 
-def test_pointwise_kernel_equals_general_kernels(cuda):
-    """1x1 / stride 1 layers CAN run on conv_pw_kernel (round 4, option 'pw' = 1): no barrier per K-step, a wave's input rows by LDS-DMA into a
-    private swizzled ring, weights in MFMA-fragment order straight from L2, pre-activation on the fragments, epilogue from
-    the MFMA layout, persistent with the operand streams running across tiles.  The default ('pw' = 0) keeps them on
-    conv_igemm_kernel / conv_pipe_kernel.  The products of an output element
-    are accumulated in the same order, so the embeddings agree bit for bit up to the sign of an activation's zero:
-    ResNet-50V2 (pre-activation, bias, shortcuts, a second output, K from 2 to 64 steps, both tile forms: 128 x 64 for
-    the early stages, 64 x 64 for the late ones; odd batches leave ragged last tiles and whole waves past the end),
-    IResNet-50's downsample shortcuts stay on the strided kernels, MobileNetV2 (ReLU6, 1x1 expansions with Cin % 64 != 0
-    stay out), NN4.small2's inception branches write channel slices (stay out) -- every network must simply agree."""
-    import torch
-    from deep_insight_face.networks.triplet import DifEmbedder
-    rng = np.random.default_rng(46)
-    for arch, n in (('resnet', 70), ('resnet', 3), ('resnet', 257), ('iresnet50', 9), ('mobilenet', 20)):
-        x = torch.from_numpy(rng.integers(0, 256, (n, 112, 112, 3), dtype=np.uint8)).cuda()
-        m = DifEmbedder(arch, 'v2', 512, (112, 112, 3), max_batch=n).init_synthetic(13)
-        m.set_input_transform(scale=1 / 255.)
-        m.set_option('sk2', 0)                 # compare the two families themselves (round 5's split-K path would take the small layers)
-        m.set_option('pw', 1)                      # off by default (slower inside the two-lane executor: r04_ablation item 3)
-        a = m.embed(x)
-        a2 = m.embed(x)
-        kernels = {k for _, k, _ in m.op_table()}
-        m.set_option('pw', 0)
-        b = m.embed(x)
-        assert not any(k.startswith('conv_pw_kernel') for _, k, _ in m.op_table())
-        assert torch.equal(a, a2)
-        assert float((a - b).abs().max()) <= 2e-6, (arch, n, float((a - b).abs().max()))
-        if arch == 'resnet':
-            assert any(k.startswith('conv_pw_kernel') for k in kernels), kernels
-            if n == 70:
-                # the development forms (other tile shapes, three stages) and the 64-channel layers the default leaves to
-                # the pipelined kernel ('dbg' bit 8 admits them): all the same bits
-                for dbg in (8, 1 | 8, 3 | 8, 5 | 8):
-                    m.set_option('pw', 1)
-                    m.set_option('dbg', dbg)
-                    c = m.embed(x)
-                    assert float((c - b).abs().max()) <= 2e-6, (dbg, float((c - b).abs().max()))
-                m.set_option('dbg', 0)
-        m.close()
-
-
 def test_two_subtile_kernel_equals_plain_kernel(cuda):
     """The short-K 3x3 layers on maps whose sides are multiples of 8 (IResNet's 64-channel 112 x 112 and 56 x 56 layers, VGG16's
     first stages, the detector's) run on conv_t2_kernel (option 't2' = 0 keeps them on the 64 x 64 kernel): a 128-pixel x 64-channel tile of two 8x8 sub-tiles per block, two

@@ -26,7 +26,7 @@ def jl(path):
 def conv_ms(stats_csv):
     ns = calls = 0
     for r in csv.DictReader(open(stats_csv)):
-        if any(k in r['Name'] for k in ('conv_igemm_kernel', 'conv_pipe_kernel', 'conv_bdp_kernel', 'conv_tn_kernel', 'conv_t2_kernel', 'conv_pw_kernel', 'conv_sk_kernel', 'conv_skp_kernel', 'conv_sk_reduce_kernel', 'conv_mt_kernel',
+        if any(k in r['Name'] for k in ('conv_igemm_kernel', 'conv_pipe_kernel', 'conv_bdp_kernel', 'conv_tn_kernel', 'conv_t2_kernel', 'conv_sk_kernel', 'conv_skp_kernel', 'conv_sk_reduce_kernel', 'conv_mt_kernel',
                                          'stem_mfma_kernel', 'stem3x3_kernel')):
             ns += float(r['TotalDurationNs'])
             calls += int(r['Calls'])
