@@ -19,7 +19,8 @@
 //                         is two 128-byte segments; same arithmetic, element by element, as conv_epilogue.
 // S is chosen on the host (sk2_plan): about two blocks per CU, at least four K-steps per share.
 // Blocks that share a weight slice (same column tile and split, different row tiles) get hardware ids congruent mod 8 --
-// one XCD, so the slice crosses the fabric once (speed only; at batch 1 the weights are 10x the activations' bytes).
+// one XCD, so the slice crosses the fabric once (speed only; at batch 1 the weights are 10x the activations' bytes) -- in
+// equal runs per XCD (sk_item).
 
 // ---- operand loaders of the deep-prefetch mainloop below.  They differ from ConvALoader / ConvPwLoader / RowLoader in two
 // ways: a K-step's pre-activation constants and bounds mask travel with ITS registers (several K-steps are in flight at
@@ -286,6 +287,22 @@ __device__ __forceinline__ void gemm_mainloop_deep(const ALoader& al, const BLoa
   }
 }
 
+// Block -> work item (c = column tile x split pair, mt = row tile).  Items are numbered c-major and dealt to the eight XCDs
+// (hardware block id mod 8) in EQUAL contiguous runs: the blocks that share a weight slice (same c) still sit on one XCD --
+// two where a run ends inside a pair -- and every XCD gets ceil(items / 8) blocks.  (Round 5's first mapping gave whole pairs
+// to XCDs, c mod 8: 20 pairs of 25 row tiles were 75 blocks on four XCDs and 50 on the other four -- 2.3 against 1.6 blocks
+// per CU, the "uneven deal" of the block traces: lives of 12 .. 25 us in one launch.)
+__device__ __forceinline__ bool sk_item(int tiles_m, int pairs, int& c, int& mt) {
+  const int W = pairs * tiles_m, per = (W + 7) >> 3;
+  const int x = blockIdx.x & 7, i = blockIdx.x >> 3;
+  const int item = x * per + i;
+  if (i >= per || item >= W) return false;
+  c = item / tiles_m;
+  mt = item - c * tiles_m;
+  return true;
+}
+__host__ inline unsigned sk_grid(int tiles_m, int pairs) { return (unsigned)(((pairs * tiles_m + 7) >> 3) * 8); }
+
 constexpr int SK_DEPTH = 5;             // K-steps in flight per block: 5 x (8 KB + 8 KB) = 80 VGPRs of operands
 constexpr int SK_DEPTH_PRE = 3;         // ... with pre-activation constants riding along (8 more VGPRs per K-step): five spilled 12-20 registers
 
@@ -294,10 +311,8 @@ __global__ __launch_bounds__(T::NT, 2) void conv_sk_kernel(const ConvArgs a, int
   static_assert(T::WM == 1 && T::WN == 1 && T::NT == 256, "split-K path: the 64 x 64 tile");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
-  const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
-  const int cq = j / tiles_m, mt = j - cq * tiles_m;
-  const int c = cq * 8 + x;                                   // (column tile, split) pair: all its row tiles on one XCD
-  if (c >= tiles_n * S) return;
+  int c, mt;                                                  // (column tile, split) pair and row tile: sk_item
+  if (!sk_item(tiles_m, tiles_n * S, c, mt)) return;
   const unsigned long long tr_t0 = a.trace ? __builtin_amdgcn_s_memrealtime() : 0;   // development aid (net.hip: option dbg = 256)
   const unsigned long long tr_c0 = a.trace ? __builtin_amdgcn_s_memtime() : 0;
   const int nt = c / S, s = c - nt * S;
@@ -338,10 +353,8 @@ __global__ __launch_bounds__(T::NT, 2) void conv_skp_kernel(const ConvArgs a, in
   static_assert(T::WM == 1 && T::WN == 1 && T::NT == 256, "split-K path: the 64 x 64 tile");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
-  const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
-  const int cq = j / tiles_m, mt = j - cq * tiles_m;
-  const int c = cq * 8 + x;
-  if (c >= tiles_n * S) return;
+  int c, mt;
+  if (!sk_item(tiles_m, tiles_n * S, c, mt)) return;
   const unsigned long long tr_t0 = a.trace ? __builtin_amdgcn_s_memrealtime() : 0;
   const unsigned long long tr_c0 = a.trace ? __builtin_amdgcn_s_memtime() : 0;
   const int nt = c / S, s = c - nt * S;
