@@ -2056,60 +2056,13 @@ static int launch_conv_tn(const ConvArgs& a, hipStream_t st) {
   return 0;
 }
 
-#include "conv_tnk.hpp"
+// (conv_tnk_kernel -- round 5: the small-batch 3x3 layers on 64 x 128 tiles x S shares, ONE block per CU, a three-K-step register
+// ring of weights per wave, two LDS patches, conv_sk_reduce_kernel behind it; bit-identical to the 64 x 64 pair up to the
+// split -- was built, measured and removed: its blocks live 18 us for 12 us of matrix work, the same as conv_skp_kernel's once
+// that kernel's blocks are dealt evenly (sk_item), and it loses where tiles x S misses the CU count (batch 12: 4.37 vs 4.06 ms).
+// profiles/r05_ablation.txt item 13 keeps the numbers and what its ISA taught about `break` in an unrolled ring loop.)
 
-constexpr int SK2_MIN_KS = 4;          // fewest K-steps a split-K share may hold (sk2_plan, tnk_plan)
-
-// conv_tnk_kernel's layers and split: linear-patch 3x3 layers with whole 128-channel column blocks whose 64 x 128 tiles
-// number no more than the CUs; S = the most shares that still leave one block per CU (each at least SK2_MIN_KS K-steps, the
-// slabs inside the workspace).  0 = not this kernel.  A pure function of the layer's shape and the batch.
-static int tnk_plan(const ConvArgs& a, int* emax_out) {
-  if ((a.off & (CONV_OFF_TNK | CONV_OFF_SK2 | CONV_OFF_BD)) || !a.w_frag || a.Cout % 128 != 0 || (a.dbg & 16384)) return 0;
-  if (a.trace && !(a.dbg & 256)) return 0;
-  const int emax = patch_applies(a);
-  if (!emax) return 0;
-  const int64_t tiles = (int64_t)((a.M + 63) / 64) * (a.Cout / 128);
-  const int KS = a.Kpad / BK;
-  const int64_t cus = num_cus();
-  if (tiles > cus || KS < SK2_MIN_KS) return 0;
-  const int64_t cap = (int64_t)a.sk_max_blocks * (int64_t)conv_slab_floats() / 4096;   // 64 x 64 slabs the workspace holds
-  int64_t S = cus / tiles;
-  if (S > KS / SK2_MIN_KS) S = KS / SK2_MIN_KS;
-  while (S > 1 && tiles * 2 * S > cap) --S;
-  if (S < 1 || tiles * 2 * S > cap) return 0;
-  // the fewest shares with the same longest share (fewer slabs for the reduce launch to read)
-  const int64_t share = (KS + S - 1) / S;
-  while (S > 1 && (KS + S - 2) / (S - 1) == share) --S;
-  *emax_out = emax;
-  return (int)S;
-}
-
-template <int EMAX>
-static int launch_conv_tnk(const ConvArgs& a, int S, hipStream_t st) {
-  void (*kern)(const ConvArgs, int, int, int) = conv_tnk_kernel<EMAX>;
-  constexpr int lds_bytes = 2 * EMAX * 128;
-  if (allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds_bytes)) return -1;
-  const int tiles_m = (a.M + 63) / 64, tiles_n = a.Cout / 128;
-  ConvArgs b = a;
-  b.fd_howo = make_fastdiv(a.Ho * a.Wo);
-  b.fd_wo = make_fastdiv(a.Wo);
-  b.fd_wp = make_fastdiv(a.W + 2);
-  b.fd_rpi = make_fastdiv(a.H + 1);
-  const unsigned grid = sk_grid(tiles_m, tiles_n * S);
-  if ((int64_t)grid > a.sk_max_blocks) b.trace = nullptr;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, st, b, S, tiles_m, tiles_n);
-  DIF_HIP(hipGetLastError());
-  hipLaunchKernelGGL(conv_sk_reduce_kernel, dim3((unsigned)(tiles_m * tiles_n * 2 * 16)), dim3(64), 0, st, b, S, tiles_n * 2);
-  DIF_HIP(hipGetLastError());
-  {
-    static std::mutex mu;
-    static std::set<std::string> names;
-    std::lock_guard<std::mutex> lock(mu);
-    g_last_kernel = names.insert(std::string("conv_tnk_kernel<64x128,") + (EMAX == PATCH_EMAX_L ? "patch168" : "patch128") +
-                                 "+Bdirect,S=" + std::to_string(S) + ">+reduce").first->c_str();
-  }
-  return 0;
-}
+constexpr int SK2_MIN_KS = 4;          // fewest K-steps a split-K share may hold (sk2_plan)
 
 // conv_t2_kernel's layers: the 8x8-tile patch layers with a SHORT K loop (the long ones have conv_bdp_kernel), weights in
 // fragment order, whole 64-channel column tiles, the lean epilogue's plain geometry (no sub-sampled first output)
@@ -2234,7 +2187,7 @@ static int launch_conv_mt_t(const ConvArgs& a, hipStream_t st) {
   b.fd_wo = make_fastdiv(a.Wo);
   b.fd_kw = make_fastdiv(a.KW);
   b.fd_taps = make_fastdiv(a.KH * a.KW);
-  const unsigned grid = (unsigned)(((tiles_n + 7) / 8) * 8 * tiles_m);
+  const unsigned grid = sk_grid(tiles_m, tiles_n);
   // (asking for more than half a CU's LDS, so that no CU is dealt two blocks while another idles: no effect, r05_ablation item 5)
   hipLaunchKernelGGL((conv_mt_kernel<NW, PRE, PW>), dim3(grid), dim3(NW * 64), 0, st, b, tiles_m, tiles_n);
   DIF_HIP(hipGetLastError());
@@ -2284,11 +2237,6 @@ template <class T>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
   if constexpr (T::BM == 64 && T::BN == 64) {
     if (const int nw = mt_plan(a)) return launch_conv_mt(a, nw, st);
-    {
-      int emax_k = 0;
-      if (const int Sk = tnk_plan(a, &emax_k))
-        return emax_k == PATCH_EMAX_L ? launch_conv_tnk<PATCH_EMAX_L>(a, Sk, st) : launch_conv_tnk<PATCH_EMAX_S>(a, Sk, st);
-    }
     if (const int S = sk2_plan(a)) {
       // 3x3 / stride 1 layers whose linear halo patch fits: the B-direct patch mainloop (dbg bit 16384 keeps the gather: A/B)
       const int emax = (!(a.off & CONV_OFF_BD) && a.w_frag && !(a.dbg & 16384)) ? patch_applies(a) : 0;

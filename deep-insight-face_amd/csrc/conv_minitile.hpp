@@ -28,10 +28,8 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_mt_kernel(const ConvArgs a, i
   __shared__ f32x4 red[NW][64];
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
-  const int ntq = j / tiles_m, mt = j - ntq * tiles_m;
-  const int nt = ntq * 8 + x;
-  if (nt >= tiles_n) return;
+  int nt, mt;                                                 // column tile (its row tiles on one XCD, equal runs per XCD: sk_item)
+  if (!sk_item(tiles_m, tiles_n, nt, mt)) return;
   const int m0 = mt * 16, n0 = nt * 16;
   const int i = lane & 15, kq = lane >> 4;
   // epilogue operands first (wave 0 only uses them): their latency hides under the K loop

@@ -256,10 +256,7 @@ __device__ __forceinline__ void gemm_mainloop_deep(const ALoader& al, const BLoa
   stage(0, ra[0], rb[0], ps[0]);
   lds_barrier();
   if (kend - kbeg <= D) {
-    // the whole share is in flight already (every batch-1 share): straight-line code, forward exits only.  (In the loop
-    // below the compiler's wait insertion merges the back edge into the header conservatively -- it re-uses a drained slot's
-    // registers as address temporaries and waits vmcnt(3) at the top of every group of D steps; harmless on a long share,
-    // but here it would hold the first MFMA until nearly all of the share's loads had landed.)
+    // the whole share is in flight already (every batch-1 share): straight-line code, forward exits only
 #pragma unroll
     for (int j = 0; j < D; ++j) {
       if (kbeg + j >= kend) break;
@@ -269,11 +266,16 @@ __device__ __forceinline__ void gemm_mainloop_deep(const ALoader& al, const BLoa
     }
     return;
   }
-  for (int k0 = kbeg; k0 < kend; k0 += D) {
+  // Whole ring revolutions first, the share's last r < D K-steps behind the loop.  (One loop with `if (k >= kend) break;`
+  // inside the unrolled revolution looks the same and is not: the compiler routes the break through the loop's latch -- a
+  // path back to the header on which the later steps of the revolution issued nothing -- and its wait insertion then prices
+  // every ring register at the header as that many loads younger than it is: the `s_waitcnt vmcnt(3)` at the top of every
+  // revolution of this loop's first form, the ring drained to one K-step.  Read off conv_tnk_kernel's ISA, r05_ablation item 13.)
+  const int kfull = kbeg + (kend - kbeg) / D * D;
+  for (int k0 = kbeg; k0 < kfull; k0 += D) {
 #pragma unroll
     for (int j = 0; j < D; ++j) {
       const int k = k0 + j;
-      if (k >= kend) break;                                  // block-uniform; an EXIT, not a join: the counted waits stay exact
       const int cur = (k - kbeg) & 1;
       // slot j was written to LDS one step ago: refill it with K-step k + D
       const uint32_t inv = ~(uint32_t)((k + D - kend) >> 31);
@@ -284,6 +286,15 @@ __device__ __forceinline__ void gemm_mainloop_deep(const ALoader& al, const BLoa
       stage(cur ^ 1, ra[(j + 1) % D], rb[(j + 1) % D], ps[(j + 1) % D]);   // K-step k + 1 (zeros past the end: never read)
       lds_barrier();
     }
+  }
+#pragma unroll
+  for (int j = 0; j < D - 1; ++j) {                          // the tail: everything it needs is in the ring already
+    const int k = kfull + j;
+    if (k >= kend) break;                                    // a forward exit
+    const int cur = (k - kbeg) & 1;
+    mfma_step(cur);
+    stage(cur ^ 1, ra[j + 1], rb[j + 1], ps[j + 1]);
+    lds_barrier();
   }
 }
 

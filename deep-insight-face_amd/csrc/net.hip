@@ -943,7 +943,7 @@ static void fold(const Net* net, const BNRef& bn, int bias, int C, std::vector<f
 // pick between kernel families the parity tests compare)
 // every key set_option accepts (dif_net_option_name: include/dif.h documents each one, and a test holds it to that)
 const char* const* Net::option_names() {
-  static const char* const names[] = {"pipe", "bdp", "stem", "patch", "patch2d", "bd", "t2", "tn", "sk2", "mt", "tnk", "bf16x3",
+  static const char* const names[] = {"pipe", "bdp", "stem", "patch", "patch2d", "bd", "t2", "tn", "sk2", "mt", "bf16x3",
                                       "bf_terms", "ysub", "lane_split", "lane_prio", "dbg", nullptr};
   return names;
 }
@@ -973,7 +973,6 @@ int Net::set_option(const char* key, int value) {
   if (!strcmp(key, "tn")) return flag(CONV_OFF_TN);
   if (!strcmp(key, "sk2")) return flag(CONV_OFF_SK2);
   if (!strcmp(key, "mt")) return flag(CONV_OFF_MT);
-  if (!strcmp(key, "tnk")) return flag(CONV_OFF_TNK);
   if (!strcmp(key, "bf16x3")) {
     if (!pre && compute_bf16x3 != (value != 0))
       return set_error("dif_net_set_option: 'bf16x3' must be chosen before dif_net_finalize");

@@ -38,7 +38,7 @@ inline FastDiv make_fastdiv(int d) {
   return f;
 }
 
-enum { CONV_OFF_PATCH = 1, CONV_OFF_PATCH2D = 2, CONV_OFF_BD = 4, CONV_OFF_T2 = 16, CONV_OFF_TN = 32, CONV_OFF_SK2 = 64, CONV_OFF_MT = 128, CONV_OFF_TNK = 256 };
+enum { CONV_OFF_PATCH = 1, CONV_OFF_PATCH2D = 2, CONV_OFF_BD = 4, CONV_OFF_T2 = 16, CONV_OFF_TN = 32, CONV_OFF_SK2 = 64, CONV_OFF_MT = 128 };
 
 struct ConvArgs {
   const float* x;       // [N,H,W,Cin] NHWC

@@ -601,33 +601,6 @@ def test_one_image_kernel_equals_other_paths(cuda, arch, head, emd, shape, n):
     m.close()
 
 
-@pytest.mark.parametrize('arch,n', [('iresnet50', 2), ('iresnet50', 5), ('iresnet100', 8), ('iresnet50', 12), ('iresnet50', 17),
-                                    ('iresnet50', 32), ('vgg16', 3)])
-def test_wide_splitk_kernel_equals_the_64x64_pair(cuda, arch, n):
-    """Round 5: the linear-patch 3x3 layers of a small batch (the reference evaluates at 12: scripts/insight_face.py:112) run on
-    conv_tnk_kernel -- 64-pixel x 128-channel tiles x S shares, one block per CU, a three-K-step register ring of weights per
-    wave, two LDS patches -- and the same reduce launch as conv_skp_kernel; option 'tnk' = 0 keeps them on the 64 x 64 pair.
-    Same products, another fixed split: equal to float32 rounding, bit-identical run to run.  The batches make the shares start
-    at every tap of a slice (a share that starts at tap 7 or 8 loads two patches in its prologue), cover 7 x 7 tiles that span
-    several images, ragged last row tiles and S = 1 (one share: the kernel as a low-occupancy whole-tile kernel)."""
-    import torch
-    from deep_insight_face.networks.triplet import DifEmbedder
-    rng = np.random.default_rng(n * 5 + len(arch))
-    x = torch.from_numpy(rng.integers(0, 256, (n, 112, 112, 3), dtype=np.uint8)).cuda()
-    m = DifEmbedder(arch, 'v2', 512, (112, 112, 3), max_batch=n).init_synthetic(19)
-    m.set_input_transform(scale=1 / 255.)
-    a = m.embed(x)
-    a2 = m.embed(x)
-    kernels = [k for _, k, _, _ in m.profile(x)]
-    assert any(k.startswith('conv_tnk_kernel') for k in kernels), kernels
-    m.set_option('tnk', 0)
-    b = m.embed(x)
-    assert not any(k.startswith('conv_tnk_kernel') for _, k, _, _ in m.profile(x))
-    assert torch.equal(a, a2)
-    assert float((a - b).abs().max()) <= 4e-6 * max(float(b.abs().max()), 1.0)
-    m.close()
-
-
 def test_small_batches_on_a_large_max_batch_model(cuda):
     """bench.py's `latency` block (and any serving process) embeds 1 / 8 / 32 images on a model finalized for hundreds: the
     small-batch kernels are chosen from the batch at hand, not from max_batch, and the result does not depend on max_batch --
@@ -644,7 +617,7 @@ def test_small_batches_on_a_large_max_batch_model(cuda):
         assert np.array_equal(a, b), n
         assert cosine_gap(a, want[:n]).max() < TOL
         kinds = {k.split('<')[0] for _, k, _, _ in big.profile(torch.from_numpy(u8[:n]).cuda())}
-        assert ('conv_mt_kernel' in kinds) if n == 1 else (kinds & {'conv_sk_kernel', 'conv_skp_kernel', 'conv_tnk_kernel'}), (n, kinds)
+        assert ('conv_mt_kernel' in kinds) if n == 1 else (kinds & {'conv_sk_kernel', 'conv_skp_kernel'}), (n, kinds)
         small.close()
     full = big.predict_on_batch(crops_u8(192, seed=10))                    # the large-batch kernels still run on it afterwards
     assert np.all(np.isfinite(full)) and full.shape == (192, 512)
