@@ -2110,9 +2110,11 @@ static int sk2_plan(const ConvArgs& a) {
   const int KS = a.Kpad / BK;
   const int64_t cus = num_cus();
   if (tiles >= 2 * cus || KS < 2 * SK2_MIN_KS) return 0;
+  if (const int force = (a.dbg >> 16) & 63) return force == 1 ? 0 : (force <= KS / SK2_MIN_KS ? force : 0);   // (dbg bits 16..21: S for every candidate layer, 1 = no split: the S sweep)
   const int64_t cap = (int64_t)a.sk_max_blocks * (int64_t)conv_slab_floats() / 4096;   // slabs the workspace holds
-  // S minimising  rounds(S) x share(S) + 0.1 S  in K-steps: rounds = blocks per CU (co-resident blocks share the CU's matrix
-  // pipes, so their K-steps add up), share = K-steps per block, and every split costs the reduce launch one more slab to read
+  // S minimising  rounds(S) x share(S) + 0.1 S  in K-steps: rounds = blocks on the busiest CU (blocks are dealt evenly --
+  // sk_item -- and co-resident blocks share the CU's matrix pipes, so their K-steps add up), share = K-steps per block, and
+  // every split costs the reduce launch one more slab to read; at most four blocks per CU (what a CU holds at once).
   int64_t S = 0;
   double best = 1e30;
   for (int64_t s = 2; s <= KS / SK2_MIN_KS && tiles * s <= 4 * cus && tiles * s <= cap; ++s) {
@@ -2122,8 +2124,34 @@ static int sk2_plan(const ConvArgs& a) {
       S = s;
     }
   }
-  // (against no split at all: rounds(1) x KS)
+  // (against no split at all: rounds(1) x KS; a tie goes to no split)
   if (S && (double)((tiles + cus - 1) / cus) * (double)KS <= best) S = 0;
+  // Where that says "no split" with more than half the CUs busy, and the chip is this forward's alone (one lane), a second
+  // look with two things the first model leaves out:
+  //   * between one and two tiles per CU no split within four blocks per CU beats the whole tiles on rounds x share (392 tiles --
+  //     the 14 x 14 stage at batch 32, the 28 x 28 stage at batch 16: two rounds either way) -- and yet half the CUs idle through
+  //     the second round.  Up to eight blocks per CU here; a grid beyond what the CUs hold at once runs in waves, each charged
+  //     6 K-steps' time for its ramp and drain.  Three shares of those layers: batch 16 5.23 -> 4.77 ms, batch 32 8.25 -> 7.86;
+  //   * just under one tile per CU (248 tiles: the 14 x 14 stage at batch 20) every block is alone on its CU and hides no load
+  //     latency: priced at 1.15 x its K-steps, two shares win: batch 20 6.82 -> 5.71 ms (IResNet-50 3.40 -> 2.90).
+  // (IResNet-100; r05_ablation item 14 has the sweeps and the wider rules that lost.)
+  if (S == 0 && 2 * tiles > cus && a.lanes <= 1 && !(a.dbg & 32768)) {         // (dbg bit 32768: off; bit 4194304: without the `alone` factor; A/B)
+    auto cost_of = [&](int64_t s) {
+      const int64_t blocks = tiles * s;
+      // a block with no neighbour on its CU hides no latency (priced on long K loops only: ResNet-50V2's short ones lose 4 % split)
+      const double alone = (blocks <= cus && KS >= 32 && !(a.dbg & 4194304)) ? 1.15 : 1.0;
+      return alone * (double)((blocks + cus - 1) / cus) * (double)((KS + s - 1) / s) + 6.0 * (double)((blocks + 4 * cus - 1) / (4 * cus)) +
+             (s > 1 ? 0.1 * (double)s : 0.0);
+    };
+    best = cost_of(1);
+    for (int64_t s = 2; s <= KS / SK2_MIN_KS && tiles * s <= 8 * cus && tiles * s <= cap; ++s) {
+      const double cost = cost_of(s);
+      if (cost < best) {
+        best = cost;
+        S = s;
+      }
+    }
+  }
   return S >= 2 ? (int)S : 0;
 }
 

@@ -1426,6 +1426,7 @@ int Net::run_op(const Op& op, Lane& L, const void* xin, int n, int layout, int d
       a.use_pipe = use_pipe;
       a.off = conv_off;
       a.dbg = conv_dbg;
+      a.lanes = lanes_active ? (int)lanes.size() : 1;
       a.bdp_mode = use_bdp == 2 ? 2 : ((use_bdp == 0 || lane_split) ? 1 : 0);
       a.trace = trace_buf ? trace_buf + trace_off[&op - ops.data()] * 8 : nullptr;
       if (op.d_w_raw && op.stem_mfma && use_stem) {

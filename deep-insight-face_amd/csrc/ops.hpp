@@ -96,6 +96,7 @@ struct ConvArgs {
   int use_pipe;         // 0: never take the software-pipelined kernel (Net option "pipe"; tests compare both paths)
   int epi_fast;         // the output takes conv.hip's lean epilogue (plain geometry, 32-bit offsets); filled by conv_run
   int dbg;              // development aid (ablation bits of the kernel under work); 0 in production
+  int lanes;            // executor lanes launching side by side (0 / 1: this forward has the chip to itself): sk2_plan's wider splits
   unsigned off;         // kernel families switched off (Net options "patch", "patch2d", "bd" = 0): CONV_OFF_* bits
   // development aid (tools/ubench/conv_trace.hip), null in the library: 4 x u64 per hardware block =
   // s_memrealtime (100 MHz) at entry / after the first mainloop / at exit, and the HW_ID register
