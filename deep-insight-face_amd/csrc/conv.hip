@@ -2060,7 +2060,7 @@ static int launch_conv_tn(const ConvArgs& a, hipStream_t st) {
 // ring of weights per wave, two LDS patches, conv_sk_reduce_kernel behind it; bit-identical to the 64 x 64 pair up to the
 // split -- was built, measured and removed: its blocks live 18 us for 12 us of matrix work, the same as conv_skp_kernel's once
 // that kernel's blocks are dealt evenly (sk_item), and it loses where tiles x S misses the CU count (batch 12: 4.37 vs 4.06 ms).
-// profiles/r05_ablation.txt item 13 keeps the numbers and what its ISA taught about `break` in an unrolled ring loop.)
+// profiles/r05_ablation.txt item 14 keeps the numbers and what its ISA taught about `break` in an unrolled ring loop.)
 
 constexpr int SK2_MIN_KS = 4;          // fewest K-steps a split-K share may hold (sk2_plan)
 

@@ -270,7 +270,7 @@ __device__ __forceinline__ void gemm_mainloop_deep(const ALoader& al, const BLoa
   // inside the unrolled revolution looks the same and is not: the compiler routes the break through the loop's latch -- a
   // path back to the header on which the later steps of the revolution issued nothing -- and its wait insertion then prices
   // every ring register at the header as that many loads younger than it is: the `s_waitcnt vmcnt(3)` at the top of every
-  // revolution of this loop's first form, the ring drained to one K-step.  Read off conv_tnk_kernel's ISA, r05_ablation item 13.)
+  // revolution of this loop's first form, the ring drained to one K-step.  Read off conv_tnk_kernel's ISA, r05_ablation item 14.)
   const int kfull = kbeg + (kend - kbeg) / D * D;
   for (int k0 = kbeg; k0 < kfull; k0 += D) {
 #pragma unroll
