@@ -530,6 +530,7 @@ def test_mfma_clock_probe(cuda):
 @pytest.mark.parametrize('arch,head,emd,shape,n', [('resnet', 'v2', 512, (112, 112, 3), 1), ('resnet', 'v2', 512, (112, 112, 3), 12),
                                                    ('resnet', 'v1', 128, (112, 112, 3), 3), ('iresnet50', 'v2', 512, (112, 112, 3), 1),
                                                    ('iresnet100', 'v2', 512, (112, 112, 3), 8), ('iresnet50', 'v2', 512, (112, 112, 3), 33),
+                                                   ('iresnet50', 'v2', 512, (112, 112, 3), 16), ('iresnet50', 'v2', 512, (112, 112, 3), 20),
                                                    ('mobilenet', 'v2', 512, (112, 112, 3), 5), ('vgg16', 'v2', 512, (112, 112, 3), 2),
                                                    ('yolov3', 'v3', 1, (416, 416, 3), 1)])
 def test_splitk_path_equals_streamk_path(cuda, arch, head, emd, shape, n):
@@ -538,7 +539,8 @@ def test_splitk_path_equals_streamk_path(cuda, arch, head, emd, shape, n):
     keeps them on round 4's kernels.  Same products, another (fixed) summation order: embeddings agree to float32 rounding,
     run to run bit-identical.  Networks cover pre-activation (ResNet50V2), PReLU + two outputs + sub-sampled first outputs +
     strided shortcuts (IResNet), ReLU6 / depthwise neighbours (MobileNetV2), the flattening fc, concat views and 18-channel
-    heads (YOLOv3-face)."""
+    heads (YOLOv3-face); batches of 16 and 20 are sk2_plan's second look (392 tiles split three ways: a grid of more blocks
+    than the CUs hold at once; 248 lone tiles split in two)."""
     import torch
     from deep_insight_face.networks.triplet import DifEmbedder
     rng = np.random.default_rng(n * 7 + len(arch))
