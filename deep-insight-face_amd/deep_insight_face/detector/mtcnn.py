@@ -15,6 +15,7 @@ layer ``head`` = [logits 2 | box 4 | landmarks 10 | zero filters], P-Net's ``con
 """
 import ctypes
 import math
+import os
 import typing
 
 import numpy as np
@@ -48,8 +49,12 @@ class MtcnnDetector:
     score -1 = empty slot."""
 
     def __init__(self, frame_hw=(480, 640), max_batch: int = 16, min_face: int = 20, thresholds=(0.6, 0.7, 0.7),
-                 cap=(64, 32, 16), factor: float = 0.709):
+                 cap=(64, 32, 16), factor: float = 0.709, streams: int = 4):
         self.h, self.w = int(frame_hw[0]), int(frame_hw[1])
+        # the pyramid's scales are independent until their candidates are merged: they run round-robin on this many HIP
+        # streams (1 = one after the other on the caller's stream); the small scales' launches do not fill the chip
+        self.n_streams = max(1, int(os.environ.get('DIF_MTCNN_STREAMS', streams)))      # (env: A/B runs of bench.py)
+        self._side = None
         self.max_batch = int(max_batch)
         self.thresholds = tuple(float(t) for t in thresholds)
         self.cap = tuple(int(c) for c in cap)
@@ -160,18 +165,33 @@ class MtcnnDetector:
         mb = torch.empty((n, S * c0, 4), **f32)
         ms = torch.empty((n, S * c0), **f32)
         mr = torch.empty((n, S * c0, 4), **f32)
-        st = N.stream_ptr()
+        main = torch.cuda.current_stream()
+        if self.n_streams > 1 and self._side is None:
+            self._side = [torch.cuda.Stream(device=dev) for _ in range(self.n_streams - 1)]
+        lanes = [main] + (self._side or [])
+        ready = torch.cuda.Event()
+        ready.record(main)                                         # frames and the merge buffers exist from here on
         for si, (sc, (hs, ws), net) in enumerate(zip(self.scales, self.sizes, self.pnets)):
-            img = torch.empty((n, hs, ws, 3), dtype=torch.uint8, device=dev)
-            N.check(N.lib.dif_area_resize(N.ptr(t), n, self.h, self.w, N.ptr(img), hs, ws, st))
-            head = net.embed(img)                                  # [n, gh, gw, 8]
-            gh, gw, ld = head.shape[1], head.shape[2], head.shape[3]
-            pb = torch.empty((n, gh * gw, 4), **f32)
-            ps = torch.empty((n, gh * gw), **f32)
-            N.check(N.lib.dif_mtcnn_propose(N.ptr(head), n, gh, gw, ld, float(sc), self.thresholds[0], N.ptr(pb), N.ptr(ps), st))
-            keep = self._nms(pb, ps, c0, 0.5)
-            reg_ptr = ctypes.c_void_p(head.data_ptr() + 2 * 4)     # the map's box channels, rows `ld` floats apart
-            self._gather(keep, c0, pb, ps, reg_ptr, ld, gh * gw, mb, ms, mr, S * c0, si * c0, 0)
+            lane = lanes[si % len(lanes)]
+            with torch.cuda.stream(lane):                          # (every launch below reads the current stream)
+                if lane is not main:
+                    lane.wait_event(ready)
+                st = N.stream_ptr()
+                img = torch.empty((n, hs, ws, 3), dtype=torch.uint8, device=dev)
+                N.check(N.lib.dif_area_resize(N.ptr(t), n, self.h, self.w, N.ptr(img), hs, ws, st))
+                head = net.embed(img)                              # [n, gh, gw, 8]
+                gh, gw, ld = head.shape[1], head.shape[2], head.shape[3]
+                pb = torch.empty((n, gh * gw, 4), **f32)
+                ps = torch.empty((n, gh * gw), **f32)
+                N.check(N.lib.dif_mtcnn_propose(N.ptr(head), n, gh, gw, ld, float(sc), self.thresholds[0], N.ptr(pb), N.ptr(ps), st))
+                keep = self._nms(pb, ps, c0, 0.5)
+                reg_ptr = ctypes.c_void_p(head.data_ptr() + 2 * 4)  # the map's box channels, rows `ld` floats apart
+                self._gather(keep, c0, pb, ps, reg_ptr, ld, gh * gw, mb, ms, mr, S * c0, si * c0, 0)
+        for lane in lanes[1:]:                                     # the merge waits for every scale
+            done = torch.cuda.Event()
+            done.record(lane)
+            main.wait_event(done)
+        st = N.stream_ptr()
         b1 = torch.empty((n, c1, 4), **f32)
         s1 = torch.empty((n, c1), **f32)
         keep = self._nms(mb, ms, c1, 0.7)

@@ -112,6 +112,26 @@ def test_cascade_vs_oracle(cuda, hw, n):
 
 
 @pytest.mark.gpu
+def test_pyramid_streams_give_the_same_detections(cuda):
+    """The pyramid's scales run round-robin on `streams` HIP streams (default 4) and meet before the merge: same boxes and
+    scores, bit for bit, as one scale after the other on the caller's stream, call after call."""
+    import torch
+    from deep_insight_face.detector.mtcnn import MtcnnDetector
+    hw, n = (120, 160), 4
+    frames = _frames(n, hw[0], hw[1], seed=11)
+    one = MtcnnDetector(hw, max_batch=n, cap=(24, 12, 8), streams=1).init_synthetic(7)
+    ref_b, ref_s = one.detect(frames)
+    for k in (2, 3, 5):
+        det = MtcnnDetector(hw, max_batch=n, cap=(24, 12, 8), streams=k)
+        det.set_weights(one.get_weights())
+        for _ in range(3):
+            b, s = det.detect(frames)
+            assert torch.equal(b, ref_b) and torch.equal(s, ref_s), k
+        det.close()
+    one.close()
+
+
+@pytest.mark.gpu
 def test_detection_wrapper_and_frame_pipeline(cuda):
     """detector/run.py:120-173's calling convention (image -> crops, boxes; ValueError when nothing is found), and the
     batched device pipeline frames -> best face -> crop -> embedding -> match, whose crops equal the per-image path's."""
