@@ -64,6 +64,8 @@ def main():
             cp('layers_%s_b%d.txt' % (a, b), '%s_%s_b%d_layers.txt' % (R, short, b))
             if os.path.exists(os.path.join(OUT, 'ksb_%s_%d.txt' % (a, b))):
                 cp('ksb_%s_%d.txt' % (a, b), '%s_%s_b%d_kernel_stats.txt' % (R, short, b))
+    if os.path.exists(os.path.join(OUT, 'ks_frames_mtcnn.txt')):
+        cp('ks_frames_mtcnn.txt', R + '_frames_mtcnn_kernel_stats.txt')
     # forwards per profiled run, in units of the workload's batch: bench.py reports them (`forwards_in_process`:
     # steps + warmup, the per-layer profile, the warm-up and the stamped forward of the clock measurement, and the
     # batch-256 forwards of the default workload)

@@ -39,6 +39,7 @@ python3 tools/layer_profile.py resnet 256 > $O/layers_r50.txt 2>&1 &&
 python3 tools/layer_profile.py iresnet100 256 bf16x2 > $O/layers_r100_bf16x2.txt 2>&1 &&
 python3 tools/layer_profile.py yolov3 64 > $O/layers_yolov3.txt 2>&1 &&
 python3 tools/latency.py > $O/latency.txt 2>&1 &&
+(rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_frames_mtcnn -o p -- python3 bench.py --workload frames_mtcnn --steps 3 --warmup 1 --no-cpu-baseline > $O/ks_frames_mtcnn.json 2> $O/ks_frames_mtcnn.err && python3 tools/kstats.py $O/ks_frames_mtcnn 4 > $O/ks_frames_mtcnn.txt) &&
 # 5b. round 5: the small-batch regime -- per-layer tables, kernel-trace stats and block traces at batch 1 / 8 / 32
 (for a in iresnet100 resnet; do for b in 1 8 32; do python3 tools/layer_profile.py $a $b > $O/layers_${a}_b$b.txt 2>&1 || exit 1; done; done) &&
 (for c in "iresnet100 1" "iresnet100 8" "iresnet100 32" "resnet 1" "resnet 8"; do set -- $c; rocprofv3 --kernel-trace --stats --output-format csv -d $O/ksb_$1_$2 -o p -- python3 tools/small_batch.py $1 $2 50 > $O/ksb_$1_$2.log 2>&1 && python3 tools/kstats.py $O/ksb_$1_$2 55 > $O/ksb_$1_$2.txt || exit 1; done) &&

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.join(ROOT, 'deep-insight-face_amd'))
 from deep_insight_face.networks.triplet import DifEmbedder  # noqa: E402
 
 for arch in ('resnet', 'iresnet100'):
-    for B in (1, 8, 32):
+    for B in (1, 8, 12, 16, 32):
         m = DifEmbedder(arch, 'v2', 512, (112, 112, 3), max_batch=B).init_synthetic()
         x = torch.randint(0, 256, (B, 112, 112, 3), dtype=torch.uint8, device='cuda')
         for _ in range(5):
