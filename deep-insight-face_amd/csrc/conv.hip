@@ -2452,6 +2452,10 @@ int conv_run(const ConvArgs& a, hipStream_t st) {
     case 5: return launch_conv_pre<Tile<2, 1, 2, 2>, false, 16, 1>(a, st);     // two 8x8 sub-tiles, 64 columns
     default: break;
   }
+  // Layers of at most 32 output channels (MTCNN's P-Net: 10 / 16 / 32 channels over 1.7 M pixels per launch; heads of 8): a
+  // 128-pixel x 32-channel tile -- four waves stacked over the pixels -- instead of 64 x 64 with half or three quarters of the
+  // MFMA columns multiplying padding.  [dbg bit 8388608: the 64 x 64 tile, A/B]
+  if (a.Cout <= 32 && !(a.dbg & 8388608)) return launch_conv<Tile<1, 1, 4, 1>>(a, st);
   return launch_conv<Tile<1, 1>>(a, st);
 }
 
