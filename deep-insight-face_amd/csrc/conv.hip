@@ -2413,7 +2413,8 @@ static int launch_conv_pre_impl(const ConvArgs& a, hipStream_t st) {
   return 0;
 }
 
-// The f32 path ships ONE tile shape: 64x64 (four blocks per CU).  Measured per layer over both networks against
+// The general f32 kernels ship the 64x64 tile (four blocks per CU) -- and, for layers of at most 32 output channels, 128 x 32
+// (the end of conv_run).  64x64 was measured per layer over both networks against
 // 128x128 / 128x64 / 64x128 at four waves (round 1: it wins or ties everywhere) and against 128x128 at eight waves
 // (round 2: within 1 % either way, profiles/r02_ablation.txt), so the other f32 instantiations were dropped.
 int conv_run(const ConvArgs& a, hipStream_t st) {
