@@ -1,5 +1,5 @@
 """The N>1 data path (all-gather of per-rank embeddings -> gallery-sharded match ->
-all-gather of partials -> lowest-index merge) with world_size 2 and 3 on the gloo
+all-gather of partials -> lowest-index merge) with world_size 2, 3 and 8 on the gloo
 backend, CPU only.  The local compute is stood in by the oracle (the HIP kernels need
 a GPU; their sharded-merge parity is covered by tests/test_match_gpu.py)."""
 import os
@@ -58,7 +58,7 @@ def _worker(rank, world, port, G, b, metric, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,metric', [(2, 1), (2, 0), (3, 1)])
+@pytest.mark.parametrize('world,metric', [(2, 1), (2, 0), (3, 1), (8, 1)])     # 8: the node bench.py's largest line runs on (1001 rows: ragged shards)
 def test_sharded_match_equals_whole(tmp_path, world, metric):
     G, b = 1001, 5
     port = _free_port()
