@@ -105,7 +105,7 @@ def main():
     for r in csv.DictReader(open(os.path.join(OUT, 'ks_default_1lane/p_kernel_stats.csv'))):
         if 'match_g1_kernel' in r['Name'] or 'match_b1_kernel' in r['Name'] or 'match_bd_kernel' in r['Name']:
             lines.append('%s in that run: %s calls, %.1f us average (kernel-trace stats) vs match phase %.3f ms by HIP events '
-                         '(the phase also holds probe_prep1 / finish / exact / output)'
+                         '(the phase also holds probe_prep1 / finish / exact)'
                          % (r['Name'].split('(')[0].split('::')[-1], r['Calls'], float(r['AverageNs']) / 1e3, one['phases_ms']['match']))
     d = jl(os.path.join(OUT, 'bench_default.json'))
     dp = jl(os.path.join(OUT, 'ks_default.json'))
